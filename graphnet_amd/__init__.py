@@ -1,0 +1,10 @@
+"""graphnet_amd — MI355X-native DynEdge message-passing path behind graphnet's plugin API.
+
+Host-side mirrors of the reference interface (``Data``/``Batch``, ``Detector``, ``KNNGraph``,
+``GNN``/``DynEdge``, ``StandardModel``, tasks, losses) sit on top of a C-ABI shared library of
+hand-written gfx950 HIP kernels (``include/graphnet_amd.h``).  Importing the package never
+needs a GPU; calling a device op without the built library raises ``RuntimeError``.
+"""
+from .data import Batch, Data, collate_fn  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,180 @@
+// graphnet_amd/csrc/cabi.hip — extern "C" surface declared in include/graphnet_amd.h.
+// Plain pointers and sizes only; argument validation lives here so that a bad shape is an
+// error code, never a faulting kernel.
+#include "../../include/graphnet_amd.h"
+#include "launchers.hpp"
+#include <cstdio>
+#include <cstring>
+
+namespace {
+thread_local char g_err[512] = "";
+int fail(hipError_t e, const char* where) {
+    if (e == hipSuccess) return 0;
+    std::snprintf(g_err, sizeof(g_err), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
+    return (int)e;
+}
+int bad(const char* where, const char* what) {
+    std::snprintf(g_err, sizeof(g_err), "%s: %s", where, what);
+    return (int)hipErrorInvalidValue;
+}
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+bool make_segs(gn::Segs& s, int nseg, const float* const* p, const int64_t* ld, const int32_t* width,
+               const int32_t* kpad) {
+    if (nseg < 1 || nseg > gn::MAXSEG) return false;
+    std::memset(&s, 0, sizeof(s));
+    s.nseg = nseg;
+    for (int i = 0; i < nseg; ++i) {
+        if (!p[i] || (reinterpret_cast<uintptr_t>(p[i]) & 15)) return false;
+        s.p[i] = p[i]; s.ld[i] = ld[i]; s.width[i] = width[i];
+        s.kpad[i] = kpad ? kpad[i] : (width[i] + gn::BK - 1) / gn::BK * gn::BK;
+    }
+    return true;
+}
+gn::EdgeGraph make_graph(const int32_t* nbr, const int32_t* oc, const int32_t* os, const int32_t* cnt, int N, int K) {
+    gn::EdgeGraph g;
+    g.nbr = nbr; g.ovf_centre = oc; g.ovf_src = os; g.ovf_cnt = cnt; g.N = N; g.K = K;
+    return g;
+}
+}  // namespace
+
+extern "C" {
+
+const char* gn_last_error(void) { return g_err; }
+int gn_abi_version(void) { return 1; }
+
+int gn_knn_graph(const float* x, int64_t ldx, const int32_t* cols_host, int32_t D, const int32_t* batch,
+                 const int32_t* ptr, int32_t N, int32_t k, int32_t strict, int32_t* nbr, int32_t* ovf, void* stream) {
+    if (N < 0 || k < 1 || k > 32 || D < 1 || D > 8 || !cols_host) return bad("gn_knn_graph", "need 1<=k<=32, 1<=D<=8");
+    if (!strict && !ovf) return bad("gn_knn_graph", "compat mode needs ovf[N]");
+    for (int d = 0; d < D; ++d) if (cols_host[d] < 0 || cols_host[d] >= ldx) return bad("gn_knn_graph", "column out of range");
+    return fail(gn::launch_knn(x, ldx, cols_host, D, batch, ptr, N, k, strict, nbr, ovf, S(stream)), "gn_knn_graph");
+}
+
+int64_t gn_scan_tmp_ints(int64_t n) { return (n + 2047) / 2048 + 1; }
+int gn_scan_i32(const int32_t* in, int32_t* out, int32_t n, int32_t* tmp, int32_t* total, void* stream) {
+    if (n < 0) return bad("gn_scan_i32", "n < 0");
+    return fail(gn::launch_scan(in, out, n, tmp, total, S(stream)), "gn_scan_i32");
+}
+int gn_ovf_compact(const int32_t* ovf, int32_t N, int32_t* work_N, int32_t* tmp, int32_t* ovf_centre,
+                   int32_t* ovf_src, int32_t* ovf_cnt, void* stream) {
+    return fail(gn::launch_ovf_compact(ovf, N, work_N, tmp, ovf_centre, ovf_src, ovf_cnt, S(stream)), "gn_ovf_compact");
+}
+int32_t gn_edge_slots(int32_t K) { return gn::edge_slots(K); }
+int gn_rev_build(const int32_t* nbr, int32_t N, int32_t K, const int32_t* ovf_src, const int32_t* ovf_cnt,
+                 int32_t* rev_ptr, int32_t* cursor, int32_t* tmp, int32_t* rev_rows, void* stream) {
+    if (K < 1 || K > 32) return bad("gn_rev_build", "need 1<=K<=32");
+    return fail(gn::launch_rev_build(nbr, N, K, gn::edge_slots(K), ovf_src, ovf_cnt, rev_ptr, cursor, tmp, rev_rows,
+                                     S(stream)), "gn_rev_build");
+}
+int gn_table_degree(const int32_t* nbr, const int32_t* ovf, int32_t N, int32_t K, int32_t* deg, void* stream) {
+    return fail(gn::launch_table_degree(nbr, ovf, N, K, deg, S(stream)), "gn_table_degree");
+}
+int gn_table_to_edge_index(const int32_t* nbr, const int32_t* ovf, int32_t N, int32_t K, const int32_t* off, int64_t E,
+                           int64_t* edge_index, void* stream) {
+    return fail(gn::launch_table_to_edges(nbr, ovf, N, K, off, E, reinterpret_cast<long long*>(edge_index), S(stream)),
+                "gn_table_to_edge_index");
+}
+int gn_edge_index_to_table(const int64_t* edge_index, int64_t E, int32_t N, int32_t K, int32_t* first_N, int32_t* nbr,
+                           int32_t* ovf, int32_t* err, void* stream) {
+    return fail(gn::launch_edges_to_table(reinterpret_cast<const long long*>(edge_index), E, N, K, first_N, nbr, ovf,
+                                          err, S(stream)), "gn_edge_index_to_table");
+}
+int gn_ptr_to_batch(const int32_t* ptr, int32_t B, int32_t* batch, void* stream) {
+    return fail(gn::launch_ptr_to_batch(ptr, B, batch, S(stream)), "gn_ptr_to_batch");
+}
+int gn_graph_globals(const float* x, int64_t ldx, int32_t F, const int32_t* ptr, int32_t B, const int32_t* nbr,
+                     const int32_t* ovf, int32_t K, const int32_t* n_pulses, float* out, void* stream) {
+    if (F < 4 || F > 32 || ldx < F) return bad("gn_graph_globals", "need 4 <= F <= 32 (columns 0-3 = x,y,z,t)");
+    return fail(gn::launch_globals(x, ldx, F, ptr, B, nbr, ovf, K, n_pulses, out, S(stream)), "gn_graph_globals");
+}
+int gn_concat_globals(const float* x, int64_t ldx, int32_t F, const float* gv, int32_t G, const int32_t* batch,
+                      int32_t N, float* x0, int32_t ld0, void* stream) {
+    if (ld0 < F + G) return bad("gn_concat_globals", "ld0 < F+G");
+    return fail(gn::launch_concat_globals(x, ldx, F, gv, G, batch, N, x0, ld0, S(stream)), "gn_concat_globals");
+}
+
+int gn_linear_fwd(int32_t mode, int32_t nseg, const float* const* a_ptr, const int64_t* a_ld, const int32_t* a_width,
+                  const int32_t* a_kpad, int32_t M, const void* Wp, int32_t Kp, int32_t Npad, int32_t Nreal,
+                  const float* bias, const float* gate, int64_t ldgate, int32_t relu, int32_t accum, void* C,
+                  int64_t ldc, int32_t out_lowp, void* stream) {
+    gn::Segs a;
+    if (!make_segs(a, nseg, a_ptr, a_ld, a_width, a_kpad)) return bad("gn_linear_fwd", "bad A segments (1..6, 16-byte aligned)");
+    if (mode != 0 && mode != 1) return bad("gn_linear_fwd", "mode");
+    if (out_lowp && (mode == 0 || accum)) return bad("gn_linear_fwd", "low-precision output needs bf16 mode, no accumulate");
+    if (Npad % 128 || Nreal > Npad || (reinterpret_cast<uintptr_t>(Wp) & 15)) return bad("gn_linear_fwd", "Wp must be [Npad%128==0][Kp], 16-byte aligned");
+    gn::Epi e;
+    e.bias = bias; e.gate = gate; e.ldgate = ldgate; e.relu = relu; e.accum = accum;
+    hipError_t r = gn::launch_gemm_nt(mode, a, M, Wp, Kp, Npad, Nreal, e, C, ldc, out_lowp, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_linear_fwd", "segment widths/pitches must be multiples of 4, kpad multiples of 32 summing to Kp");
+    return fail(r, "gn_linear_fwd");
+}
+int32_t gn_linear_wgrad_splits(int32_t M) { return gn::gemm_tn_splits(M); }
+int gn_linear_wgrad(int32_t mode, const float* dY, int64_t lddy, int32_t N1, int32_t nseg, const float* const* x_ptr,
+                    const int64_t* x_ld, const int32_t* x_width, int32_t M, float* slab, float* dW, int32_t accum,
+                    void* stream) {
+    gn::Segs x;
+    if (!make_segs(x, nseg, x_ptr, x_ld, x_width, nullptr)) return bad("gn_linear_wgrad", "bad X segments");
+    if (reinterpret_cast<uintptr_t>(dY) & 15) return bad("gn_linear_wgrad", "dY must be 16-byte aligned");
+    hipError_t r = gn::launch_gemm_tn(mode, dY, lddy, N1, x, M, slab, dW, accum, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_linear_wgrad", "widths/pitches/N1 must be multiples of 4");
+    return fail(r, "gn_linear_wgrad");
+}
+int32_t gn_colsum_blocks(int32_t M) { return gn::colsum_blocks(M); }
+int gn_colsum(const float* X, int64_t ld, int32_t M, int32_t C, float* part, float* out, int32_t accum, void* stream) {
+    return fail(gn::launch_colsum(X, ld, M, C, part, out, accum, S(stream)), "gn_colsum");
+}
+int gn_reduce_slabs(const float* slab, int32_t nslab, int64_t count, float* out, int32_t accum, void* stream) {
+    return fail(gn::launch_reduce_slabs(slab, nslab, count, out, accum, S(stream)), "gn_reduce_slabs");
+}
+
+int gn_edgeconv_fwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
+                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, const void* W2p,
+                    const float* b2, int32_t H2, float* out, int64_t ldo, uint32_t* maskbits, void* stream) {
+    if (K < 1 || K > 32 || H1p % 32 || H2 < 1) return bad("gn_edgeconv_fwd", "need 1<=K<=32, H1p%32==0");
+    if ((reinterpret_cast<uintptr_t>(PQ) & 15) || (reinterpret_cast<uintptr_t>(W2p) & 15)) return bad("gn_edgeconv_fwd", "alignment");
+    return fail(gn::launch_edge_fwd(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, W2p, b2, H2, out,
+                                    ldo, maskbits, S(stream)), "gn_edgeconv_fwd");
+}
+int gn_edgeconv_bwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
+                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H2,
+                    const float* gout, int64_t ldg, const uint32_t* maskbits, const void* W2Tp, int32_t H2p, void* dpre,
+                    float* dP, int64_t ldp, void* stream) {
+    if (K < 1 || K > 32 || H1p % 32 || H2p % 32 || H2p < H2 || (ldg & 3) || (reinterpret_cast<uintptr_t>(gout) & 15))
+        return bad("gn_edgeconv_bwd", "need 1<=K<=32, H1p%32==0, H2p%32==0, gout 16-byte aligned with pitch%4==0");
+    return fail(gn::launch_edge_bwd(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, H2, gout, ldg,
+                                    maskbits, W2Tp, H2p, dpre, dP, ldp, S(stream)), "gn_edgeconv_bwd");
+}
+int32_t gn_edgeconv_dw2_splits(int64_t rows) { return (int32_t)gn::edge_dw2_splits(rows); }
+int gn_edgeconv_dw2(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
+                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H1, int32_t H2,
+                    const float* gout, int64_t ldg, const uint32_t* maskbits, float* slab, float* db2_part,
+                    int32_t splits, void* stream) {
+    if (K < 1 || K > 32 || H1p % 32 || H1 > H1p || (ldg & 3) || (H2 & 3) || splits < 1 || N < 1)
+        return bad("gn_edgeconv_dw2", "bad shapes");
+    return fail(gn::launch_edge_dw2(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, H1, H2, gout, ldg,
+                                    maskbits, slab, db2_part, splits, S(stream)), "gn_edgeconv_dw2");
+}
+int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int32_t* rev_ptr, const int32_t* rev_rows,
+                          int32_t N, float* dQ, int64_t ldq, void* stream) {
+    hipError_t r = gn::launch_dq_gather(mode, dpre, H1p, rev_ptr, rev_rows, N, dQ, ldq, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_edgeconv_dq_gather", "need H1p <= 512, H1p%4==0, ldq%4==0");
+    return fail(r, "gn_edgeconv_dq_gather");
+}
+
+int gn_segment_pool_fwd(const float* x, int64_t ldx, int32_t C, const int32_t* ptr, int32_t B, const int32_t* codes_host,
+                        int32_t ns, float* out, int32_t* argmin, int32_t* argmax, void* stream) {
+    hipError_t r = gn::launch_pool_fwd(x, ldx, C, ptr, B, codes_host, ns, out, argmin, argmax, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_segment_pool_fwd", "1..4 pooling schemes");
+    return fail(r, "gn_segment_pool_fwd");
+}
+int gn_segment_pool_bwd(const float* gout, int32_t C, const int32_t* ptr, const int32_t* batch, int32_t N,
+                        const int32_t* codes_host, int32_t ns, const int32_t* argmin, const int32_t* argmax,
+                        const float* gate, int64_t ldgate, float* dx, int64_t lddx, void* stream) {
+    hipError_t r = gn::launch_pool_bwd(gout, C, ptr, batch, N, codes_host, ns, argmin, argmax, gate, ldgate, dx, lddx,
+                                       S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_segment_pool_bwd", "1..4 pooling schemes");
+    return fail(r, "gn_segment_pool_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+// graphnet_amd/csrc/common.hpp — shared device helpers for the gfx950 (CDNA4, wave64) kernels.
+//
+// Conventions used by every GEMM-shaped kernel in this directory:
+//   * compute type T is `float` (exact-f32 parity mode, v_mfma_f32_32x32x2_f32) or
+//     `__bf16` (fast mode, v_mfma_f32_32x32x16_bf16); accumulation is always fp32.
+//   * operand tiles live in LDS as [rows][BK] of T with K contiguous and every row padded by
+//     16 bytes (ROWB = BK*sizeof(T)+16): a wave's ds_read_b128 fragment reads then touch 16
+//     distinct 16-byte slots per lane group (conflict-free, MI355X_MICROARCH §LDS).
+//   * one "k-step" = 32 bytes of a row: 16 bf16 (one 32x32x16 MFMA) or 8 f32 (four 32x32x2
+//     MFMAs, lane-half h taking k = 8s+4h+t so A and B agree on the k permutation).
+//   * accumulator tile 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;  // K elements per LDS block
+
+template <typename T> struct TileCfg {
+    static constexpr int ROWB = BK * (int)sizeof(T) + 16;        // padded row pitch in bytes
+    static constexpr int KSTEPS = BK * (int)sizeof(T) / 32;      // 32-byte k-steps per block
+};
+
+// 16-byte fragment of one lane for one k-step
+template <typename T> struct Frag;
+template <> struct Frag<float> { f32x4 v; };
+template <> struct Frag<__bf16> { bf16x8 v; };
+
+template <typename T>
+__device__ __forceinline__ Frag<T> lds_frag(const unsigned char* tile, int row, int kstep, int half) {
+    Frag<T> f;
+    const unsigned char* p = tile + row * TileCfg<T>::ROWB + kstep * 32 + half * 16;
+    if constexpr (sizeof(T) == 4) f.v = *reinterpret_cast<const f32x4*>(p);
+    else f.v = *reinterpret_cast<const bf16x8*>(p);
+    return f;
+}
+
+__device__ __forceinline__ void mma(const Frag<float>& a, const Frag<float>& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[0], b.v[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[1], b.v[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[2], b.v[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[3], b.v[3], c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(const Frag<__bf16>& a, const Frag<__bf16>& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
+}
+
+// row of accumulator register r for lane-half h inside a 32x32 tile
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// One BK-deep block of MFMAs for a wave that owns TM x TN tiles of 32x32.
+// a_tile/b_tile: LDS tiles; a_row0/b_row0: first row of this wave's sub-tile.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void mma_block(const unsigned char* a_tile, const unsigned char* b_tile,
+                                          int a_row0, int b_row0, int lane, f32x16 (&acc)[TM][TN]) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < TileCfg<T>::KSTEPS; ++s) {
+        Frag<T> fa[TM], fb[TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) fa[m] = lds_frag<T>(a_tile, a_row0 + m * 32 + r, s, h);
+#pragma unroll
+        for (int n = 0; n < TN; ++n) fb[n] = lds_frag<T>(b_tile, b_row0 + n * 32 + r, s, h);
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) mma(fa[m], fb[n], acc[m][n]);
+    }
+}
+
+// ---- scalar/vector conversions -------------------------------------------------------
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+// store 4 consecutive T values (converted from fp32) at p (8- or 16-byte aligned)
+template <typename T> __device__ __forceinline__ void store4(void* p, float a, float b, float c, float d) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+    } else {
+        bf16x4 v;
+        v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+        *reinterpret_cast<bf16x4*>(p) = v;
+    }
+}
+// load 4 consecutive T values as fp32
+template <typename T> __device__ __forceinline__ float4 load4(const void* p) {
+    if constexpr (sizeof(T) == 4) {
+        return *reinterpret_cast<const float4*>(p);
+    } else {
+        bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+}
+
+template <typename T> __device__ __forceinline__ void zero_acc(T& a) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = 0.0f;
+}
+
+// A operand made of up to MAXSEG column segments (skip-cat without materialising the cat):
+// segment s contributes `width` real columns, padded to `kpad` (multiple of BK) in K space.
+constexpr int MAXSEG = 6;
+struct Segs {
+    const float* p[MAXSEG];
+    long long ld[MAXSEG];
+    int width[MAXSEG];
+    int kpad[MAXSEG];
+    int nseg;
+};
+
+// epilogue of the NT GEMM
+struct Epi {
+    const float* bias;      // [N] or null
+    const float* gate;      // [M, ldgate] or null: output *= (gate > 0)
+    long long ldgate;
+    int relu;               // max(v, 0)
+    int accum;              // C += v (fp32 outputs only)
+};
+
+// neighbour table + overflow list of one layer's graph
+struct EdgeGraph {
+    const int* nbr;        // [N, K]
+    const int* ovf_centre; // [<=N]
+    const int* ovf_src;    // [<=N]
+    const int* ovf_cnt;    // [1] device-side count of overflow rows
+    int N, K;
+};
+
+}  // namespace gn

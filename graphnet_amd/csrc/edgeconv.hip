@@ -1,0 +1,591 @@
+// graphnet_amd/csrc/edgeconv.hip — fused EdgeConv (aggr = add) forward / backward.
+//
+// Reference op (models/components/layers.py:55-60 -> torch_geometric.nn.EdgeConv):
+//     out[i] = sum_{(j->i)} act( W2 . act( W1 . [x_i || x_j - x_i] + b1 ) + b2 )
+// Algebraic split used here (SURVEY.md §7 "algebraic shortcut"; rounding differs from the
+// reference formulation only in the first linear map, checked at 1e-4 in fp32 mode):
+//     W1 . [x_i || x_j - x_i] + b1 = P[i] + Q[j],  P = x (W1a - W1b)^T + b1,  Q = x W1b^T
+// P|Q is one per-node GEMM (gemm.hip); this file holds the per-edge part:
+//
+//   edge_fwd    h = relu(P[i]+Q[j]) built on the fly into the LDS A-tile (gather, never in HBM)
+//               -> MFMA with W2 -> +b2, relu -> segmented sum over each centre's slots
+//               (in-register + one cross-half shuffle, no atomics) -> out[N,H2];
+//               also stores 1 bit per (edge row, column) of the second relu for backward.
+//   edge_bwd    dm = g_out[i] (.) bit -> MFMA with W2^T -> (.) [P[i]+Q[j] > 0] = dpre
+//               -> segmented slot sum -> dP[i]; dpre rows go to HBM once for the dQ scatter.
+//   edge_dw2    dW2 += dm^T . h over all edge rows (contraction over rows; split + slabs),
+//               db2 partials.
+//   dq_gather   dQ[j] = sum of dpre rows that gathered from j, in ascending row order
+//               (reverse adjacency, deterministic).
+//
+// Edge rows: fixed-stride neighbour table nbr[N,K] (-1 padded) viewed as N*S rows, S = slots
+// per centre (8/16/32 >= K); the rare (K+1)-th neighbour of the k+1-then-mask semantics is an
+// "overflow" row t (centre ovf_centre[t], source ovf_src[t]) processed by the OVF variants.
+#include "common.hpp"
+
+namespace gn {
+
+constexpr int EBM = 128;   // edge rows per workgroup tile
+constexpr int EBN = 128;   // output columns per workgroup tile
+
+
+// decode edge row -> (centre, source); source = -1 for empty slots / out of range
+template <int S, bool OVF>
+__device__ __forceinline__ void row_decode(const EdgeGraph& g, long long row, int& ic, int& jc) {
+    ic = 0; jc = -1;
+    if constexpr (OVF) {
+        if (row < *g.ovf_cnt) { ic = g.ovf_centre[row]; jc = g.ovf_src[row]; }
+    } else {
+        const long long i = row / S;
+        const int s = (int)(row % S);
+        if (i < g.N) {
+            ic = (int)i;
+            if (s < g.K) jc = g.nbr[i * g.K + s];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ forward
+template <typename T, int S, bool OVF>
+__global__ __launch_bounds__(256) void edge_fwd_kernel(
+    EdgeGraph g, const T* __restrict__ PQ, int H1p,            // PQ: [N, 2*H1p], P then Q
+    const T* __restrict__ W2p, const float* __restrict__ b2, int H2,   // W2p: [H2pad128][H1p]
+    float* __restrict__ out, long long ldo,                    // [N, H2] (+= for OVF)
+    unsigned int* __restrict__ maskbits)                       // [rows][H2w], H2w = ceil(H2/32)
+{
+    constexpr int ROWB = TileCfg<T>::ROWB;
+    constexpr int BCHROW = BK * (int)sizeof(T) / 16;
+    constexpr int BCH = EBN * BCHROW / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char As[EBM * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[EBN * ROWB];
+    __shared__ int s_ic[EBM], s_jc[EBM];
+
+    const long long row0 = (long long)blockIdx.x * EBM;
+    if constexpr (OVF) { if (row0 >= *g.ovf_cnt) return; }
+    const int n0 = blockIdx.y * EBN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int H2w = (H2 + 31) >> 5;
+    const long long ldpq = 2LL * H1p;
+
+    if (tid < EBM) {
+        int ic, jc;
+        row_decode<S, OVF>(g, row0 + tid, ic, jc);
+        s_ic[tid] = ic; s_jc[tid] = jc;
+    }
+    __syncthreads();
+
+    const int c4 = (tid & 7) * 4, r0 = tid >> 3;
+    int ic[4], jc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ic[i] = s_ic[r0 + 32 * i]; jc[i] = s_jc[r0 + 32 * i]; }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) zero_acc(acc[i][j]);
+
+    f32x4 hreg[4];
+    u32x4 breg[BCH];
+    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(W2p);
+#define GN_EF_LOAD(kb)                                                                                    \
+    {                                                                                                     \
+        const int kc = (kb) * BK + c4;                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+            f32x4 h = {0.f, 0.f, 0.f, 0.f};                                                               \
+            if (jc[i] >= 0) {                                                                             \
+                const float4 p = load4<T>(PQ + (long long)ic[i] * ldpq + kc);                             \
+                const float4 q = load4<T>(PQ + (long long)jc[i] * ldpq + H1p + kc);                       \
+                h[0] = fmaxf(p.x + q.x, 0.f); h[1] = fmaxf(p.y + q.y, 0.f);                               \
+                h[2] = fmaxf(p.z + q.z, 0.f); h[3] = fmaxf(p.w + q.w, 0.f);                               \
+            }                                                                                             \
+            hreg[i] = h;                                                                                  \
+        }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                 \
+            const int ch = tid + 256 * i;                                                                 \
+            breg[i] = *reinterpret_cast<const u32x4*>(                                                    \
+                wbytes + ((long long)(n0 + ch / BCHROW) * H1p + (kb) * BK) * sizeof(T) + (ch % BCHROW) * 16); \
+        }                                                                                                 \
+    }
+
+    const int nkb = H1p / BK;
+    GN_EF_LOAD(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            store4<T>(As + (r0 + 32 * i) * ROWB + c4 * sizeof(T), hreg[i][0], hreg[i][1], hreg[i][2], hreg[i][3]);
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int ch = tid + 256 * i;
+            *reinterpret_cast<u32x4*>(Bs + (ch / BCHROW) * ROWB + (ch % BCHROW) * 16) = breg[i];
+        }
+        __syncthreads();
+        if (kb + 1 < nkb) GN_EF_LOAD(kb + 1);
+        mma_block<T, 2, 2>(As, Bs, wr * 64, wc * 64, lane, acc);
+    }
+#undef GN_EF_LOAD
+
+    // ---- epilogue: +b2, relu, validity, relu bits, slot sum
+    const int h = lane >> 5, cl = lane & 31;
+    const int rL = (cl & 3) + 4 * (cl >> 3), hL = (cl >> 2) & 1;   // (reg, half) holding row cl
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const int rbase = wr * 64 + tm * 32;                        // first local row of this 32x32 tile
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n0 + wc * 64 + tn * 32 + cl;
+            const bool colok = col < H2;
+            const float b = colok ? b2[col] : 0.0f;
+            float v[16];
+            unsigned int word = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = rbase + acc_row(r, h);
+                const bool ok = colok && s_jc[rl] >= 0;
+                v[r] = ok ? fmaxf(acc[tm][tn][r] + b, 0.0f) : 0.0f;
+                const unsigned long long bal = __ballot(v[r] > 0.0f);
+                if (r == rL) word = hL ? (unsigned int)(bal >> 32) : (unsigned int)bal;
+            }
+            if (lane < 32) {
+                const long long rowglob = (OVF ? (long long)g.N * S : 0LL) + row0 + rbase + cl;
+                const int cw = (n0 + wc * 64 + tn * 32) >> 5;
+                const bool rowok = OVF ? (row0 + rbase + cl < *g.ovf_cnt) : (row0 + rbase + cl < (long long)g.N * S);
+                if (rowok && cw < H2w) maskbits[rowglob * H2w + cw] = word;
+            }
+            if constexpr (OVF) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = rbase + acc_row(r, h);
+                    if (colok && s_jc[rl] >= 0) out[(long long)s_ic[rl] * ldo + col] += v[r];
+                }
+            } else {
+                constexpr int CPT = 32 / S;          // centres per 32-row tile
+                constexpr int RPC = 16 / CPT;        // accumulator registers per centre per lane
+                const long long c0 = (row0 + rbase) / S;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < RPC; ++q) s += v[c * RPC + q];
+                    s += __shfl_xor(s, 32);
+                    const bool mine = (CPT == 1) ? (h == 0) : ((c * 2 / CPT) == h);
+                    if (mine && colok && c0 + c < g.N) out[(c0 + c) * ldo + col] = s;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ backward (dh)
+template <typename T, int S, bool OVF>
+__global__ __launch_bounds__(256) void edge_bwd_kernel(
+    EdgeGraph g, const T* __restrict__ PQ, int H1p, int H2,
+    const float* __restrict__ gout, long long ldg,             // [N, >=H2] gradient of conv output
+    const unsigned int* __restrict__ maskbits,
+    const T* __restrict__ W2Tp,                                // [H1pad128][H2p] (W2 transposed, packed)
+    int H2p,                                                   // H2 padded to 32
+    T* __restrict__ dpre,                                      // [rows][H1p]
+    float* __restrict__ dP, long long ldp)                     // [N, H1p] (= / += for OVF)
+{
+    constexpr int ROWB = TileCfg<T>::ROWB;
+    constexpr int BCHROW = BK * (int)sizeof(T) / 16;
+    constexpr int BCH = EBN * BCHROW / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char As[EBM * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[EBN * ROWB];
+    __shared__ int s_ic[EBM], s_jc[EBM];
+
+    const long long row0 = (long long)blockIdx.x * EBM;
+    if constexpr (OVF) { if (row0 >= *g.ovf_cnt) return; }
+    const int n0 = blockIdx.y * EBN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int H2w = (H2 + 31) >> 5;
+    const long long ldpq = 2LL * H1p;
+    const long long rowbase = (OVF ? (long long)g.N * S : 0LL) + row0;
+
+    if (tid < EBM) {
+        int ic, jc;
+        row_decode<S, OVF>(g, row0 + tid, ic, jc);
+        s_ic[tid] = ic; s_jc[tid] = jc;
+    }
+    __syncthreads();
+
+    const int c4 = (tid & 7) * 4, r0 = tid >> 3;
+    int ic[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ic[i] = s_ic[r0 + 32 * i]; ok[i] = s_jc[r0 + 32 * i] >= 0; }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) zero_acc(acc[i][j]);
+
+    f32x4 areg[4];
+    u32x4 breg[BCH];
+    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(W2Tp);
+#define GN_EB_LOAD(kb)                                                                                    \
+    {                                                                                                     \
+        const int kc = (kb) * BK + c4;                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};                                                               \
+            if (ok[i] && kc < H2) {                                                                       \
+                const unsigned int w = maskbits[(rowbase + r0 + 32 * i) * H2w + (kb)] >> c4;              \
+                const float4 gv = *reinterpret_cast<const float4*>(gout + (long long)ic[i] * ldg + kc);   \
+                a[0] = (w & 1u) ? gv.x : 0.f; a[1] = (w & 2u) ? gv.y : 0.f;                               \
+                a[2] = (w & 4u) ? gv.z : 0.f; a[3] = (w & 8u) ? gv.w : 0.f;                               \
+            }                                                                                             \
+            areg[i] = a;                                                                                  \
+        }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                 \
+            const int ch = tid + 256 * i;                                                                 \
+            breg[i] = *reinterpret_cast<const u32x4*>(                                                    \
+                wbytes + ((long long)(n0 + ch / BCHROW) * H2p + (kb) * BK) * sizeof(T) + (ch % BCHROW) * 16); \
+        }                                                                                                 \
+    }
+
+    const int nkb = H2p / BK;
+    GN_EB_LOAD(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            store4<T>(As + (r0 + 32 * i) * ROWB + c4 * sizeof(T), areg[i][0], areg[i][1], areg[i][2], areg[i][3]);
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int ch = tid + 256 * i;
+            *reinterpret_cast<u32x4*>(Bs + (ch / BCHROW) * ROWB + (ch % BCHROW) * 16) = breg[i];
+        }
+        __syncthreads();
+        if (kb + 1 < nkb) GN_EB_LOAD(kb + 1);
+        mma_block<T, 2, 2>(As, Bs, wr * 64, wc * 64, lane, acc);
+    }
+#undef GN_EB_LOAD
+
+    const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const int rbase = wr * 64 + tm * 32;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n0 + wc * 64 + tn * 32 + cl;
+            const bool colok = col < H1p;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = rbase + acc_row(r, h);
+                const int j = s_jc[rl];
+                float d = 0.0f;
+                if (colok && j >= 0) {
+                    const float pre = to_f32(PQ[(long long)s_ic[rl] * ldpq + col]) +
+                                      to_f32(PQ[(long long)j * ldpq + H1p + col]);
+                    d = pre > 0.0f ? acc[tm][tn][r] : 0.0f;
+                }
+                v[r] = d;
+                const long long rg = row0 + rl;
+                const bool rowok = OVF ? (rg < *g.ovf_cnt) : (rg < (long long)g.N * S);
+                if (colok && rowok) dpre[(rowbase + rl) * H1p + col] = from_f32<T>(d);
+            }
+            if constexpr (OVF) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = rbase + acc_row(r, h);
+                    if (colok && s_jc[rl] >= 0) dP[(long long)s_ic[rl] * ldp + col] += v[r];
+                }
+            } else {
+                constexpr int CPT = 32 / S, RPC = 16 / CPT;
+                const long long c0 = (row0 + rbase) / S;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < RPC; ++q) s += v[c * RPC + q];
+                    s += __shfl_xor(s, 32);
+                    const bool mine = (CPT == 1) ? (h == 0) : ((c * 2 / CPT) == h);
+                    if (mine && colok && c0 + c < g.N) dP[(c0 + c) * ldp + col] = s;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ dW2 / db2
+// slab[split][n2][k1] = sum over this split's edge rows of dm[row][n2] * h[row][k1]
+// Rows enumerate the table rows [0, N*S) followed by the overflow rows [N*S, N*S + cnt).
+template <typename T, int S>
+__global__ __launch_bounds__(256) void edge_dw2_kernel(
+    EdgeGraph g, const T* __restrict__ PQ, int H1p, int H1, int H2,
+    const float* __restrict__ gout, long long ldg, const unsigned int* __restrict__ maskbits,
+    long long rows_per_split, float* __restrict__ slab, float* __restrict__ db2_part, int n2_tiles)
+{
+    constexpr int ROWB = TileCfg<T>::ROWB;
+    constexpr int BT = 128;
+    constexpr int RS = ROWB / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) unsigned char As[BT * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[BT * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int t2 = blockIdx.x % n2_tiles, tk = blockIdx.x / n2_tiles;
+    const int n2_0 = t2 * BT, k1_0 = tk * BT;
+    const int split = blockIdx.y;
+    const int H2w = (H2 + 31) >> 5;
+    const long long ldpq = 2LL * H1p;
+    const long long main_rows = (long long)g.N * S;
+    const long long total_rows = main_rows + (g.ovf_cnt ? *g.ovf_cnt : 0);
+    const long long rbeg = split * rows_per_split;
+    const long long rend = min(total_rows, rbeg + rows_per_split);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) zero_acc(acc[i][j]);
+    float bsum[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bsum[i] = 0.0f;
+
+    const int mr = tid >> 3, cb = (tid & 7) * 4;
+    f32x4 ra[4], rb[4];
+#define GN_DW_LOAD(rb0)                                                                                   \
+    {                                                                                                     \
+        const long long row = (rb0) + mr;                                                                 \
+        int ic = 0, jc = -1;                                                                              \
+        if (row < rend) {                                                                                 \
+            if (row < main_rows) row_decode<S, false>(g, row, ic, jc);                                    \
+            else { ic = g.ovf_centre[row - main_rows]; jc = g.ovf_src[row - main_rows]; }                 \
+        }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};                                     \
+            const int ca = n2_0 + cb + 32 * i;                                                            \
+            const int ck = k1_0 + cb + 32 * i;                                                            \
+            if (jc >= 0 && ca < H2) {                                                                     \
+                const unsigned int w = maskbits[row * H2w + (ca >> 5)] >> (ca & 31);                      \
+                const float4 gv = *reinterpret_cast<const float4*>(gout + (long long)ic * ldg + ca);      \
+                a[0] = (w & 1u) ? gv.x : 0.f; a[1] = (w & 2u) ? gv.y : 0.f;                               \
+                a[2] = (w & 4u) ? gv.z : 0.f; a[3] = (w & 8u) ? gv.w : 0.f;                               \
+            }                                                                                             \
+            if (jc >= 0 && ck < H1p) {                                                                    \
+                const float4 p = load4<T>(PQ + (long long)ic * ldpq + ck);                                \
+                const float4 q = load4<T>(PQ + (long long)jc * ldpq + H1p + ck);                          \
+                b[0] = fmaxf(p.x + q.x, 0.f); b[1] = fmaxf(p.y + q.y, 0.f);                               \
+                b[2] = fmaxf(p.z + q.z, 0.f); b[3] = fmaxf(p.w + q.w, 0.f);                               \
+            }                                                                                             \
+            ra[i] = a; rb[i] = b;                                                                         \
+        }                                                                                                 \
+    }
+
+    if (rbeg < rend) GN_DW_LOAD(rbeg);
+    for (long long r0 = rbeg; r0 < rend; r0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = cb + 32 * i;
+            T* pa = reinterpret_cast<T*>(As + c * ROWB) + mr;
+            T* pb = reinterpret_cast<T*>(Bs + c * ROWB) + mr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const T av = from_f32<T>(ra[i][q]);
+                pa[q * RS] = av;
+                pb[q * RS] = from_f32<T>(rb[i][q]);
+                bsum[i * 4 + q] += ra[i][q];
+            }
+        }
+        __syncthreads();
+        if (r0 + BK < rend) GN_DW_LOAD(r0 + BK);
+        mma_block<T, 2, 2>(As, Bs, wr * 64, wc * 64, lane, acc);
+    }
+#undef GN_DW_LOAD
+
+    const int h = lane >> 5, cl = lane & 31;
+    const long long Ks = H1;                                  // slab row pitch = real H1
+    float* out = slab + (long long)split * H2 * Ks;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kc = k1_0 + wc * 64 + j * 32 + cl;
+            if (kc >= H1) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n2 = n2_0 + wr * 64 + i * 32 + acc_row(r, h);
+                if (n2 < H2) out[(long long)n2 * Ks + kc] = acc[i][j][r];
+            }
+        }
+    // db2 partial: column sums of dm over this split (only the k1-tile-0 workgroups write it).
+    // 32 row-threads x 128 columns are reduced through As in two halves of 16 rows (8 KB).
+    if (tk == 0) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(As);
+        for (int half = 0; half < 2; ++half) {
+            if ((mr >> 4) == half) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[(mr & 15) * 128 + cb + 32 * i + q] = bsum[i * 4 + q];
+            }
+            __syncthreads();
+            if (tid < 128) {
+                float s = 0.0f;
+                for (int r = 0; r < 16; ++r) s += red[r * 128 + tid];
+                const int n2 = n2_0 + tid;
+                if (n2 < H2) {
+                    float* dst = db2_part + (long long)split * H2 + n2;
+                    *dst = half ? *dst + s : s;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ dQ gather
+// dQ[j][:] = sum of dpre rows listed in rev_rows[rev_ptr[j]..rev_ptr[j+1]) in ascending row id.
+template <typename T>
+__global__ __launch_bounds__(256) void dq_gather_kernel(const T* __restrict__ dpre, int H1p,
+                                                        const int* __restrict__ rev_ptr, const int* __restrict__ rev_rows,
+                                                        int N, float* __restrict__ dQ, long long ldq) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= N) return;
+    const int lo = rev_ptr[j], hi = rev_ptr[j + 1];
+    constexpr int NC = 2;                                     // column passes: lane*4 + 256*c
+    float4 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int last = -1;
+    for (int t = lo; t < hi; ++t) {
+        // next row id in ascending order: min over entries > last
+        int best = 0x7fffffff;
+        for (int e = lo + lane; e < hi; e += 64) {
+            const int r = rev_rows[e];
+            if (r > last && r < best) best = r;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+        last = best;
+        const T* row = dpre + (long long)best * H1p;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = lane * 4 + 256 * c;
+            if (col < H1p) {
+                const float4 v = load4<T>(row + col);
+                acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = lane * 4 + 256 * c;
+        if (col < H1p) *reinterpret_cast<float4*>(dQ + (long long)j * ldq + col) = acc[c];
+    }
+}
+
+}  // namespace gn
+
+// =============================================================== host launchers
+namespace gn {
+
+static inline int cdiv__(long long a, long long b) { return (int)((a + b - 1) / b); }
+int edge_slots(int K) { return K <= 8 ? 8 : (K <= 16 ? 16 : 32); }
+long long edge_dw2_splits(long long rows) {
+    long long s = (rows + 4095) / 4096;
+    if (s < 1) s = 1;
+    if (s > 512) s = 512;
+    return s;
+}
+
+#define GN_DISPATCH_S(S_, CALL)            \
+    switch (S_) {                          \
+        case 8: { constexpr int S = 8; CALL; } break;   \
+        case 16: { constexpr int S = 16; CALL; } break; \
+        default: { constexpr int S = 32; CALL; } break; \
+    }
+
+template <typename T>
+static hipError_t edge_fwd_t(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
+                             float* out, long long ldo, unsigned int* maskbits, hipStream_t st) {
+    if (g.N == 0) return hipSuccess;
+    const int S_ = edge_slots(g.K);
+    const int ny = cdiv__(H2, EBN);
+    GN_DISPATCH_S(S_, {
+        hipLaunchKernelGGL((edge_fwd_kernel<T, S, false>), dim3(cdiv__((long long)g.N * S, EBM), ny), dim3(256), 0, st,
+                           g, (const T*)PQ, H1p, (const T*)W2p, b2, H2, out, ldo, maskbits);
+        if (g.ovf_cnt)
+            hipLaunchKernelGGL((edge_fwd_kernel<T, S, true>), dim3(cdiv__(g.N, EBM), ny), dim3(256), 0, st,
+                               g, (const T*)PQ, H1p, (const T*)W2p, b2, H2, out, ldo, maskbits);
+    });
+    return hipGetLastError();
+}
+hipError_t launch_edge_fwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2,
+                           int H2, float* out, long long ldo, unsigned int* maskbits, hipStream_t st) {
+    if (H1p % BK || g.K > 32) return hipErrorInvalidValue;
+    return mode == 0 ? edge_fwd_t<float>(g, PQ, H1p, W2p, b2, H2, out, ldo, maskbits, st)
+                     : edge_fwd_t<__bf16>(g, PQ, H1p, W2p, b2, H2, out, ldo, maskbits, st);
+}
+
+template <typename T>
+static hipError_t edge_bwd_t(const EdgeGraph& g, const void* PQ, int H1p, int H2, const float* gout, long long ldg,
+                             const unsigned int* maskbits, const void* W2Tp, int H2p, void* dpre, float* dP,
+                             long long ldp, hipStream_t st) {
+    if (g.N == 0) return hipSuccess;
+    const int S_ = edge_slots(g.K);
+    const int ny = cdiv__(H1p, EBN);
+    GN_DISPATCH_S(S_, {
+        hipLaunchKernelGGL((edge_bwd_kernel<T, S, false>), dim3(cdiv__((long long)g.N * S, EBM), ny), dim3(256), 0, st,
+                           g, (const T*)PQ, H1p, H2, gout, ldg, maskbits, (const T*)W2Tp, H2p, (T*)dpre, dP, ldp);
+        if (g.ovf_cnt)
+            hipLaunchKernelGGL((edge_bwd_kernel<T, S, true>), dim3(cdiv__(g.N, EBM), ny), dim3(256), 0, st,
+                               g, (const T*)PQ, H1p, H2, gout, ldg, maskbits, (const T*)W2Tp, H2p, (T*)dpre, dP, ldp);
+    });
+    return hipGetLastError();
+}
+hipError_t launch_edge_bwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H2, const float* gout,
+                           long long ldg, const unsigned int* maskbits, const void* W2Tp, int H2p, void* dpre,
+                           float* dP, long long ldp, hipStream_t st) {
+    if (H1p % BK || H2p % BK || g.K > 32 || (ldg & 3)) return hipErrorInvalidValue;
+    return mode == 0 ? edge_bwd_t<float>(g, PQ, H1p, H2, gout, ldg, maskbits, W2Tp, H2p, dpre, dP, ldp, st)
+                     : edge_bwd_t<__bf16>(g, PQ, H1p, H2, gout, ldg, maskbits, W2Tp, H2p, dpre, dP, ldp, st);
+}
+
+// slab >= splits*H2*H1 floats, db2_part >= splits*H2 floats; reductions are the caller's
+// (launch_reduce_slabs in gemm.hip) so that they can be fused with other slab reductions.
+template <typename T>
+static hipError_t edge_dw2_t(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
+                             long long ldg, const unsigned int* maskbits, float* slab, float* db2_part, int splits,
+                             hipStream_t st) {
+    const int S_ = edge_slots(g.K);
+    const long long rows = (long long)g.N * S_ + g.N;         // upper bound incl. overflow rows
+    long long rps = (rows + splits - 1) / splits;
+    rps = (rps + BK - 1) / BK * BK;
+    const int n2t = cdiv__(H2, 128), kt = cdiv__(H1, 128);
+    GN_DISPATCH_S(S_, {
+        hipLaunchKernelGGL((edge_dw2_kernel<T, S>), dim3(n2t * kt, splits), dim3(256), 0, st,
+                           g, (const T*)PQ, H1p, H1, H2, gout, ldg, maskbits, rps, slab, db2_part, n2t);
+    });
+    return hipGetLastError();
+}
+hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
+                           long long ldg, const unsigned int* maskbits, float* slab, float* db2_part, int splits,
+                           hipStream_t st) {
+    if (g.N == 0) return hipErrorInvalidValue;
+    return mode == 0 ? edge_dw2_t<float>(g, PQ, H1p, H1, H2, gout, ldg, maskbits, slab, db2_part, splits, st)
+                     : edge_dw2_t<__bf16>(g, PQ, H1p, H1, H2, gout, ldg, maskbits, slab, db2_part, splits, st);
+}
+
+hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows, int N,
+                            float* dQ, long long ldq, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    if (H1p > 512 || (H1p & 3) || (ldq & 3)) return hipErrorInvalidValue;
+    if (mode == 0)
+        hipLaunchKernelGGL((dq_gather_kernel<float>), dim3(cdiv__(N, 4)), dim3(256), 0, st, (const float*)dpre, H1p,
+                           rev_ptr, rev_rows, N, dQ, ldq);
+    else
+        hipLaunchKernelGGL((dq_gather_kernel<__bf16>), dim3(cdiv__(N, 4)), dim3(256), 0, st, (const __bf16*)dpre, H1p,
+                           rev_ptr, rev_rows, N, dQ, ldq);
+    return hipGetLastError();
+}
+
+}  // namespace gn

@@ -1,0 +1,314 @@
+// graphnet_amd/csrc/gemm.hip — per-node dense contractions on MFMA.
+//
+//   gemm_nt   C[M,N]  = epi( sum_seg A_seg[M,K_seg] . W[N, K]^T + bias )      (torch.nn.Linear)
+//             A is a list of fp32 column segments (skip-cat without the cat, dynedge.py:327-331),
+//             W is pre-packed as T[Npad][Kpad] with every segment padded to a multiple of 32.
+//   gemm_tn   dW[N1,K] = sum_m dY[m,N1] . X_seg[m,K]          (weight gradients, split over m,
+//             per-split slabs reduced in fixed order -> bitwise reproducible)
+//   colsum / reduce_slabs   bias gradients and the split reductions.
+//
+// Tiling: 256 threads = 4 waves (2x2), BM x BN x 32 LDS tiles, 32x32 MFMA accumulators.
+#include "common.hpp"
+
+namespace gn {
+
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // blocks are dealt round-robin over 8 XCDs: give each XCD a contiguous run of tiles
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <typename T, int BM, int BN, typename OutT>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __restrict__ Wp, int Kp, int Nreal,
+                                                      Epi epi, OutT* __restrict__ C, long long ldc, int ntn) {
+    constexpr int ROWB = TileCfg<T>::ROWB;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int ACH = BM / 32;                               // float4 loads of A per thread
+    constexpr int BCHROW = BK * (int)sizeof(T) / 16;           // 16-byte chunks per W row
+    constexpr int BCH = BN * BCHROW / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char As[BM * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * ROWB];
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm_ = tile / ntn, tn_ = tile % ntn;
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) zero_acc(acc[i][j]);
+
+    const int c4 = (tid & 7) * 4, r0 = tid >> 3;
+    float4 areg[ACH];
+    u32x4 breg[BCH];
+
+    int seg = 0, kin = 0, kglob = 0;   // current block: segment, offset inside it, offset in Kp
+    const float* ap = a.p[0];
+    long long ald = a.ld[0];
+    int awidth = a.width[0], akpad = a.kpad[0];
+#define GN_GEMM_LOAD_REGS()                                                                              \
+    {                                                                                                    \
+        const bool colok = (kin + c4) < awidth;                                                          \
+        _Pragma("unroll") for (int i = 0; i < ACH; ++i) {                                                \
+            const int row = m0 + r0 + 32 * i;                                                            \
+            areg[i] = (colok && row < M)                                                                 \
+                          ? *reinterpret_cast<const float4*>(ap + (long long)row * ald + kin + c4)       \
+                          : make_float4(0.f, 0.f, 0.f, 0.f);                                             \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                \
+            const int ch = tid + 256 * i;                                                                \
+            const int row = ch / BCHROW, cc = ch % BCHROW;                                               \
+            breg[i] = *reinterpret_cast<const u32x4*>(wbytes + ((long long)(n0 + row) * Kp + kglob) * sizeof(T) + cc * 16); \
+        }                                                                                                \
+    }
+    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(Wp);
+
+    const int nkb = Kp / BK;
+    GN_GEMM_LOAD_REGS();
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ACH; ++i)
+            store4<T>(As + (r0 + 32 * i) * ROWB + c4 * sizeof(T), areg[i].x, areg[i].y, areg[i].z, areg[i].w);
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int ch = tid + 256 * i;
+            *reinterpret_cast<u32x4*>(Bs + (ch / BCHROW) * ROWB + (ch % BCHROW) * 16) = breg[i];
+        }
+        __syncthreads();
+        if (kb + 1 < nkb) {
+            kin += BK; kglob += BK;
+            if (kin >= akpad) {
+                kin = 0; ++seg;
+#pragma unroll
+                for (int s = 1; s < MAXSEG; ++s)   // static indexing keeps the arg struct out of scratch
+                    if (s == seg) { ap = a.p[s]; ald = a.ld[s]; awidth = a.width[s]; akpad = a.kpad[s]; }
+            }
+            GN_GEMM_LOAD_REGS();
+        }
+        mma_block<T, TM, TN>(As, Bs, wr * (BM / 2), wc * (BN / 2), lane, acc);
+    }
+
+#undef GN_GEMM_LOAD_REGS
+    const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wc * (BN / 2) + j * 32 + cl;
+            if (col >= Nreal) continue;
+            const float b = epi.bias ? epi.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * (BM / 2) + i * 32 + acc_row(r, h);
+                if (row >= M) continue;
+                float v = acc[i][j][r] + b;
+                if (epi.relu) v = fmaxf(v, 0.0f);
+                if (epi.gate && !(epi.gate[(long long)row * epi.ldgate + col] > 0.0f)) v = 0.0f;
+                OutT* dst = C + (long long)row * ldc + col;
+                if constexpr (sizeof(OutT) == 4) {
+                    if (epi.accum) v += *dst;
+                    *dst = v;
+                } else {
+                    *dst = from_f32<OutT>(v);
+                }
+            }
+        }
+}
+
+// dW slab[split][n1][kcol] = sum over this split's rows m of dY[m][n1] * X[m][kcol]
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dY, long long lddy, int N1,
+                                                      Segs x, int M, int rows_per_split,
+                                                      float* __restrict__ slab, int Ktot, int n1_tiles) {
+    constexpr int ROWB = TileCfg<T>::ROWB;
+    constexpr int BT = 128;
+    __shared__ __attribute__((aligned(16))) unsigned char As[BT * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[BT * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // blockIdx.x -> (n1 tile, k tile); k tiles enumerate 128-column pieces of each segment
+    const int t1 = blockIdx.x % n1_tiles;
+    int tk = blockIdx.x / n1_tiles;
+    int kcol0 = 0, kout0 = 0, xw = 0;
+    const float* xp = nullptr;
+    long long ldx = 0;
+    bool found = false;
+#pragma unroll
+    for (int s = 0; s < MAXSEG; ++s) {
+        if (s < x.nseg && !found) {
+            const int nt = (x.width[s] + BT - 1) / BT;
+            if (tk < nt) { kcol0 = tk * BT; xp = x.p[s]; ldx = x.ld[s]; xw = x.width[s]; found = true; }
+            else { tk -= nt; kout0 += x.width[s]; }
+        }
+    }
+    if (!found) return;
+    const int n1_0 = t1 * BT;
+    const int split = blockIdx.y;
+    const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) zero_acc(acc[i][j]);
+
+    const int mr = tid >> 3;             // 0..31: contraction row inside the block
+    const int cb = (tid & 7) * 4;        // column quad inside each 32-wide group
+    float4 ra[4], rb[4];
+    auto load_regs = [&](int mb) {
+        const int m = mb + mr;
+        const bool mok = m < mend;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ca = n1_0 + cb + 32 * i;
+            ra[i] = (mok && ca < N1) ? *reinterpret_cast<const float4*>(dY + (long long)m * lddy + ca)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int cx = kcol0 + cb + 32 * i;
+            rb[i] = (mok && cx < xw) ? *reinterpret_cast<const float4*>(xp + (long long)m * ldx + cx)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (mbeg < mend) load_regs(mbeg);
+    for (int mb = mbeg; mb < mend; mb += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = cb + 32 * i;
+            T* pa = reinterpret_cast<T*>(As + c * ROWB) + mr;
+            T* pb = reinterpret_cast<T*>(Bs + c * ROWB) + mr;
+            constexpr int RS = ROWB / (int)sizeof(T);
+            pa[0] = from_f32<T>(ra[i].x); pa[RS] = from_f32<T>(ra[i].y);
+            pa[2 * RS] = from_f32<T>(ra[i].z); pa[3 * RS] = from_f32<T>(ra[i].w);
+            pb[0] = from_f32<T>(rb[i].x); pb[RS] = from_f32<T>(rb[i].y);
+            pb[2 * RS] = from_f32<T>(rb[i].z); pb[3 * RS] = from_f32<T>(rb[i].w);
+        }
+        __syncthreads();
+        if (mb + BK < mend) load_regs(mb + BK);
+        mma_block<T, 2, 2>(As, Bs, wr * 64, wc * 64, lane, acc);
+    }
+
+    const int h = lane >> 5, cl = lane & 31;
+    float* out = slab + (long long)split * N1 * Ktot;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kc = kcol0 + wc * 64 + j * 32 + cl;
+            if (kc >= xw) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n1 = n1_0 + wr * 64 + i * 32 + acc_row(r, h);
+                if (n1 < N1) out[(long long)n1 * Ktot + kout0 + kc] = acc[i][j][r];
+            }
+        }
+}
+
+// out[i] (+)= sum_s slab[s][i]   (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int nslab, long long count,
+                                                           float* __restrict__ out, int accum) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.0f;
+    for (int k = 0; k < nslab; ++k) s += slab[(long long)k * count + i];
+    out[i] = accum ? out[i] + s : s;
+}
+
+// part[blk][c] = sum over rows of block blk of X[r][c]
+constexpr int COLSUM_ROWS = 512;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long long ld, int M, int C,
+                                                     float* __restrict__ part) {
+    const int rbeg = blockIdx.x * COLSUM_ROWS, rend = min(M, rbeg + COLSUM_ROWS);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.0f;
+        for (int r = rbeg; r < rend; ++r) s += X[(long long)r * ld + c];
+        part[(long long)blockIdx.x * C + c] = s;
+    }
+}
+
+}  // namespace gn
+
+// =============================================================== host launchers
+namespace gn {
+
+static inline int cdiv_(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+template <typename T, typename OutT>
+static hipError_t launch_gemm_nt_t(const Segs& a, int M, const void* Wp, int Kp, int Npad, int Nreal, const Epi& epi,
+                                   void* C, long long ldc, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    constexpr int BM = 128, BN = 128;
+    const int ntn = cdiv_(Nreal, BN);
+    if (ntn * BN > Npad) return hipErrorInvalidValue;
+    const int ntm = cdiv_(M, BM);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, OutT>), dim3(ntm * ntn), dim3(256), 0, st, a, M,
+                       reinterpret_cast<const T*>(Wp), Kp, Nreal, epi, reinterpret_cast<OutT*>(C), ldc, ntn);
+    return hipGetLastError();
+}
+
+// mode: 0 = f32 operands, 1 = bf16 operands.  out_lowp: write C in the operand type.
+hipError_t launch_gemm_nt(int mode, const Segs& a, int M, const void* Wp, int Kp, int Npad, int Nreal, const Epi& epi,
+                          void* C, long long ldc, int out_lowp, hipStream_t st) {
+    int ksum = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        if (a.kpad[s] % BK || a.width[s] > a.kpad[s] || (a.width[s] & 3) || (a.ld[s] & 3)) return hipErrorInvalidValue;
+        ksum += a.kpad[s];
+    }
+    if (ksum != Kp) return hipErrorInvalidValue;
+    if (mode == 0) return launch_gemm_nt_t<float, float>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+    if (out_lowp) return launch_gemm_nt_t<__bf16, __bf16>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+    return launch_gemm_nt_t<__bf16, float>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+}
+
+int gemm_tn_splits(int M) {
+    int s = cdiv_(M, 2048);
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return s;
+}
+
+// dW[N1, Ktot] (+)= dY^T . [X_seg0 | X_seg1 | ...];  slab: >= splits*N1*Ktot floats
+hipError_t launch_gemm_tn(int mode, const float* dY, long long lddy, int N1, const Segs& x, int M, float* slab,
+                          float* dW, int accum, hipStream_t st) {
+    int Ktot = 0, ktiles = 0;
+    for (int s = 0; s < x.nseg; ++s) {
+        if ((x.width[s] & 3) || (x.ld[s] & 3)) return hipErrorInvalidValue;
+        Ktot += x.width[s];
+        ktiles += cdiv_(x.width[s], 128);
+    }
+    if ((lddy & 3) || (N1 & 3)) return hipErrorInvalidValue;
+    const int splits = gemm_tn_splits(M);
+    int rps = cdiv_(M > 0 ? M : 1, splits);
+    rps = cdiv_(rps, BK) * BK;
+    const int n1t = cdiv_(N1, 128);
+    dim3 grid(n1t * ktiles, splits);
+    if (mode == 0)
+        hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, st, dY, lddy, N1, x, M, rps, slab, Ktot, n1t);
+    else
+        hipLaunchKernelGGL((gemm_tn_kernel<__bf16>), grid, dim3(256), 0, st, dY, lddy, N1, x, M, rps, slab, Ktot, n1t);
+    const long long count = (long long)N1 * Ktot;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(count, 256)), dim3(256), 0, st, slab, splits, count, dW, accum);
+    return hipGetLastError();
+}
+
+int colsum_blocks(int M) { return cdiv_(M > 0 ? M : 1, COLSUM_ROWS); }
+
+// out[c] (+)= sum_r X[r][c];  part: >= colsum_blocks(M)*C floats
+hipError_t launch_colsum(const float* X, long long ld, int M, int C, float* part, float* out, int accum, hipStream_t st) {
+    const int nb = colsum_blocks(M);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, X, ld, M, C, part);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(C, 256)), dim3(256), 0, st, part, nb, (long long)C, out, accum);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_slabs(const float* slab, int nslab, long long count, float* out, int accum, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(count, 256)), dim3(256), 0, st, slab, nslab, count, out, accum);
+    return hipGetLastError();
+}
+
+}  // namespace gn

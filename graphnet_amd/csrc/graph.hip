@@ -1,0 +1,440 @@
+// graphnet_amd/csrc/graph.hip — graph construction kernels over the batched-CSR layout.
+//
+//   knn_kernel          per-event brute-force k-NN, candidates staged through LDS in chunks,
+//                       one query per lane with a register-resident sorted (d2, j) list.
+//                       Replaces torch_cluster.knn behind torch_geometric.nn.knn_graph at
+//                       models/graphs/edges/edges.py:74-78 and models/components/layers.py:63-67.
+//   ovf_*               deterministic compaction of the (k+1)-th "overflow" neighbours.
+//   rev_*               reverse adjacency (who gathers from node j) for the backward scatter.
+//   globals_kernel      homophily x4 + per-event feature means + log10(n_pulses)
+//                       (models/gnn/dynedge.py:266-293, models/utils.py:13-29).
+//   scan                exclusive int32 scan used by the compaction / reverse-CSR builders.
+//
+// HBM-bound integer/byte work: no MFMA here.  Arithmetic that decides k-NN order is kept
+// free of FMA contraction so that it is bit-identical to oracle/knn_oracle.c.
+#include "common.hpp"
+
+namespace gn {
+
+constexpr int KNN_DMAX = 8;
+constexpr int KNN_CH = 1024;   // candidates per LDS chunk
+constexpr int KNN_BLOCK = 256;
+
+struct KnnCols { int c[KNN_DMAX]; };
+
+template <int KMAX>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(
+    const float* __restrict__ x, long long ldx, KnnCols cols, int D,
+    const int* __restrict__ batch, const int* __restrict__ ptr, int N,
+    int k, int strict, int* __restrict__ nbr, int* __restrict__ ovf)
+{
+#pragma clang fp contract(off)
+    __shared__ float cand[KNN_DMAX][KNN_CH];
+    const int q = blockIdx.x * KNN_BLOCK + threadIdx.x;
+    const bool active = q < N;
+    const int q0 = blockIdx.x * KNN_BLOCK;
+    const int qlast = min(q0 + KNN_BLOCK, N) - 1;
+    const int blo = ptr[batch[q0]];
+    const int bhi = ptr[batch[qlast] + 1];
+
+    int mylo = 0, myhi = 0;
+    float qc[KNN_DMAX];
+#pragma unroll
+    for (int d = 0; d < KNN_DMAX; ++d) qc[d] = 0.0f;
+    if (active) {
+        const int b = batch[q];
+        mylo = ptr[b];
+        myhi = ptr[b + 1];
+#pragma unroll
+        for (int d = 0; d < KNN_DMAX; ++d)
+            if (d < D) qc[d] = x[(long long)q * ldx + cols.c[d]];
+    }
+    // wave-uniform scan bounds
+    int wlo = active ? mylo : 0x7fffffff, whi = active ? myhi : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        wlo = min(wlo, __shfl_xor(wlo, o));
+        whi = max(whi, __shfl_xor(whi, o));
+    }
+
+    float bd[KMAX];
+    int bj[KMAX];
+#pragma unroll
+    for (int e = 0; e < KMAX; ++e) { bd[e] = 1e10f; bj[e] = -1; }
+    const int kk = strict ? k : k + 1;
+
+    for (int c0 = blo; c0 < bhi; c0 += KNN_CH) {
+        const int cn = min(KNN_CH, bhi - c0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cn; t += KNN_BLOCK) {
+            const float* row = x + (long long)(c0 + t) * ldx;
+#pragma unroll
+            for (int d = 0; d < KNN_DMAX; ++d)
+                if (d < D) cand[d][t] = row[cols.c[d]];
+        }
+        __syncthreads();
+        const int jb = max(c0, wlo), je = min(c0 + cn, whi);
+        for (int j = jb; j < je; ++j) {
+            float d2 = 0.0f;
+#pragma unroll
+            for (int d = 0; d < KNN_DMAX; ++d) {
+                if (d < D) {
+                    const float diff = cand[d][j - c0] - qc[d];
+                    const float sq = diff * diff;
+                    d2 = d2 + sq;
+                }
+            }
+            const bool ok = active && j >= mylo && j < myhi && !(strict && j == q);
+            // kk-th best is the admission threshold; list beyond kk is never consulted
+            if (ok && bd[KMAX - 1] > d2) {
+#pragma unroll
+                for (int t = KMAX - 1; t > 0; --t) {
+                    const float prev = bd[t - 1];
+                    if (prev > d2) { bd[t] = prev; bj[t] = bj[t - 1]; }
+                    else if (bd[t] > d2) { bd[t] = d2; bj[t] = j; }
+                }
+                if (bd[0] > d2) { bd[0] = d2; bj[0] = j; }
+            }
+        }
+    }
+    if (!active) return;
+    int c = 0;
+    int extra = -1;
+#pragma unroll
+    for (int e = 0; e < KMAX; ++e) {
+        if (e < kk) {
+            const int j = bj[e];
+            if (j >= 0 && j != q) {
+                if (c < k) nbr[(long long)q * k + c] = j;
+                else extra = j;
+                ++c;
+            }
+        }
+    }
+    for (; c < k; ++c) nbr[(long long)q * k + c] = -1;
+    if (ovf) ovf[q] = extra;
+}
+
+// ---------------------------------------------------------------- exclusive scan (int32)
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;   // per thread -> 2048 per block
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* lds) {
+    // lds: SCAN_BLOCK/64 ints
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) lds[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_BLOCK / 64; ++i) {
+        const int s = lds[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_phase1(const int* __restrict__ in, int n,
+                                                          int* __restrict__ out, int* __restrict__ bsum) {
+    __shared__ int lds[SCAN_BLOCK / 64];
+    const int base = (blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+    int v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = (base + i < n) ? in[base + i] : 0; s += v[i]; }
+    int tot;
+    int ex = block_exclusive_scan(s, &tot, lds);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_phase2(int* __restrict__ bsum, int nb, int* __restrict__ total_out) {
+    __shared__ int lds[SCAN_BLOCK / 64];
+    int carry = 0;
+    for (int c0 = 0; c0 < nb; c0 += SCAN_BLOCK) {
+        const int i = c0 + threadIdx.x;
+        const int v = (i < nb) ? bsum[i] : 0;
+        int tot;
+        const int ex = block_exclusive_scan(v, &tot, lds);
+        if (i < nb) bsum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_phase3(int* __restrict__ out, int n, const int* __restrict__ bsum) {
+    const int base = (blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+    const int add = bsum[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) out[base + i] += add;
+}
+
+// ---------------------------------------------------------------- overflow compaction
+__global__ __launch_bounds__(256) void flag_nonneg(const int* __restrict__ v, int n, int* __restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flag[i] = v[i] >= 0 ? 1 : 0;
+}
+// pos = exclusive scan of flags; writes centre ids (ascending) and their overflow sources
+__global__ __launch_bounds__(256) void ovf_write(const int* __restrict__ ovf, const int* __restrict__ pos, int n,
+                                                 int* __restrict__ ovf_centre, int* __restrict__ ovf_src) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && ovf[i] >= 0) { ovf_centre[pos[i]] = i; ovf_src[pos[i]] = ovf[i]; }
+}
+
+// ---------------------------------------------------------------- reverse adjacency
+// rows: r = i*S + slot for the fixed-stride table (S slots per centre), r = N*S + t for
+// overflow edge t.  cnt[j] += 1 for each row whose source is j.
+__global__ __launch_bounds__(256) void rev_count(const int* __restrict__ nbr, int N, int K, int S,
+                                                 const int* __restrict__ ovf_src, const int* __restrict__ ovf_cnt,
+                                                 int* __restrict__ cnt) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long main_rows = (long long)N * S;
+    if (t < main_rows) {
+        const int i = (int)(t / S), s = (int)(t % S);
+        if (s < K) { const int j = nbr[(long long)i * K + s]; if (j >= 0) atomicAdd(&cnt[j], 1); }
+    } else if (ovf_cnt && t - main_rows < *ovf_cnt) {
+        atomicAdd(&cnt[ovf_src[t - main_rows]], 1);
+    }
+}
+__global__ __launch_bounds__(256) void rev_fill(const int* __restrict__ nbr, int N, int K, int S,
+                                                const int* __restrict__ ovf_src, const int* __restrict__ ovf_cnt,
+                                                const int* __restrict__ rev_ptr, int* __restrict__ cursor,
+                                                int* __restrict__ rev_rows) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long main_rows = (long long)N * S;
+    int j = -1;
+    if (t < main_rows) {
+        const int i = (int)(t / S), s = (int)(t % S);
+        if (s < K) j = nbr[(long long)i * K + s];
+    } else if (ovf_cnt && t - main_rows < *ovf_cnt) {
+        j = ovf_src[t - main_rows];
+    }
+    if (j >= 0) {
+        const int p = atomicAdd(&cursor[j], 1);
+        rev_rows[rev_ptr[j] + p] = (int)t;
+    }
+}
+
+// ---------------------------------------------------------------- edge_index <-> table
+__global__ __launch_bounds__(256) void table_degree(const int* __restrict__ nbr, const int* __restrict__ ovf,
+                                                    int N, int K, int* __restrict__ deg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    int c = 0;
+    for (int s = 0; s < K; ++s) c += nbr[(long long)i * K + s] >= 0;
+    if (ovf) c += ovf[i] >= 0;
+    deg[i] = c;
+}
+__global__ __launch_bounds__(256) void table_to_edges(const int* __restrict__ nbr, const int* __restrict__ ovf,
+                                                      int N, int K, const int* __restrict__ off, long long E,
+                                                      long long* __restrict__ edge_index) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    long long e = off[i];
+    for (int s = 0; s < K; ++s) {
+        const int j = nbr[(long long)i * K + s];
+        if (j >= 0) { edge_index[e] = j; edge_index[E + e] = i; ++e; }
+    }
+    if (ovf && ovf[i] >= 0) { edge_index[e] = ovf[i]; edge_index[E + e] = i; }
+}
+// edges sorted by target (edge_index[1] ascending, as knn_graph emits them): the e-th edge of
+// centre i goes to slot e - first[i]; slot K goes to ovf; deeper slots are counted in *err.
+__global__ __launch_bounds__(256) void edges_first(const long long* __restrict__ dst, long long E, int* __restrict__ first) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    if (e == 0 || dst[e - 1] != dst[e]) first[dst[e]] = (int)e;
+}
+__global__ __launch_bounds__(256) void edges_to_table(const long long* __restrict__ src, const long long* __restrict__ dst,
+                                                      long long E, const int* __restrict__ first, int K,
+                                                      int* __restrict__ nbr, int* __restrict__ ovf, int* __restrict__ err) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int i = (int)dst[e];
+    const int s = (int)(e - first[i]);
+    if (e > 0 && dst[e - 1] > dst[e]) atomicAdd(err, 1);          // not sorted by target
+    if (s < K) nbr[(long long)i * K + s] = (int)src[e];
+    else if (s == K) ovf[i] = (int)src[e];
+    else atomicAdd(err, 1);                                        // degree > K+1
+}
+
+// ---------------------------------------------------------------- global variables
+// One wave per event.  out[g, 0:F] = mean_i x[i,:], out[g, F+c] = homophily of column c
+// (c = 0..3; exact float equality over edges j->i of the event), out[g, F+4] = log10(n).
+__global__ __launch_bounds__(256) void globals_kernel(
+    const float* __restrict__ x, long long ldx, int F, const int* __restrict__ ptr, int B,
+    const int* __restrict__ nbr, const int* __restrict__ ovf, int K,
+    const int* __restrict__ n_pulses, float* __restrict__ out)
+{
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= B) return;
+    const int lo = ptr[g], hi = ptr[g + 1];
+    constexpr int FMAX = 32;
+    float sum[FMAX];
+#pragma unroll
+    for (int f = 0; f < FMAX; ++f) sum[f] = 0.0f;
+    int match[4] = {0, 0, 0, 0};
+    int edges = 0;
+    for (int i = lo + lane; i < hi; i += 64) {
+        const float* xi = x + (long long)i * ldx;
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) if (f < F) sum[f] += xi[f];
+        const float a0 = xi[0], a1 = xi[1], a2 = xi[2], a3 = xi[3];
+        for (int s = 0; s <= K; ++s) {
+            int j;
+            if (s < K) j = nbr[(long long)i * K + s];
+            else j = ovf ? ovf[i] : -1;
+            if (j < 0) continue;
+            const float* xj = x + (long long)j * ldx;
+            ++edges;
+            match[0] += (xj[0] == a0);
+            match[1] += (xj[1] == a1);
+            match[2] += (xj[2] == a2);
+            match[3] += (xj[3] == a3);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) if (f < F) sum[f] += __shfl_xor(sum[f], o);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) match[c] += __shfl_xor(match[c], o);
+        edges += __shfl_xor(edges, o);
+    }
+    if (lane == 0) {
+        const int G = F + 5;
+        float* o = out + (long long)g * G;
+        const float cnt = (float)max(hi - lo, 1);
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) if (f < F) o[f] = sum[f] / cnt;
+        const float ne = (float)max(edges, 1);
+        for (int c = 0; c < 4; ++c) o[F + c] = (float)match[c] / ne;
+        o[F + 4] = log10f((float)n_pulses[g]);
+    }
+}
+
+// x0[i, 0:F] = x[i,:], x0[i, F:F+G] = gv[batch[i], :], zero padding up to ld0 columns.
+__global__ __launch_bounds__(256) void concat_globals(const float* __restrict__ x, long long ldx, int F,
+                                                      const float* __restrict__ gv, int G,
+                                                      const int* __restrict__ batch, int N,
+                                                      float* __restrict__ x0, int ld0) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(t / ld0), c = (int)(t % ld0);
+    if (i >= N) return;
+    float v = 0.0f;
+    if (c < F) v = x[(long long)i * ldx + c];
+    else if (c < F + G) v = gv[(long long)batch[i] * G + (c - F)];
+    x0[(long long)i * ld0 + c] = v;
+}
+
+__global__ __launch_bounds__(256) void ptr_to_batch(const int* __restrict__ ptr, int B, int* __restrict__ batch) {
+    const int g = blockIdx.x;
+    for (int i = ptr[g] + threadIdx.x; i < ptr[g + 1]; i += 256) batch[i] = g;
+}
+
+}  // namespace gn
+
+// =============================================================== host launchers (C++ linkage)
+namespace gn {
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+hipError_t launch_knn(const float* x, long long ldx, const int* cols, int D, const int* batch, const int* ptr,
+                      int N, int k, int strict, int* nbr, int* ovf, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    KnnCols kc;
+    for (int d = 0; d < KNN_DMAX; ++d) kc.c[d] = d < D ? cols[d] : 0;
+    const int kk = strict ? k : k + 1;
+    dim3 grid(cdiv(N, KNN_BLOCK)), block(KNN_BLOCK);
+    if (kk <= 9) hipLaunchKernelGGL(knn_kernel<9>, grid, block, 0, st, x, ldx, kc, D, batch, ptr, N, k, strict, nbr, ovf);
+    else if (kk <= 17) hipLaunchKernelGGL(knn_kernel<17>, grid, block, 0, st, x, ldx, kc, D, batch, ptr, N, k, strict, nbr, ovf);
+    else hipLaunchKernelGGL(knn_kernel<33>, grid, block, 0, st, x, ldx, kc, D, batch, ptr, N, k, strict, nbr, ovf);
+    return hipGetLastError();
+}
+
+// out[i] = sum_{t<i} in[i]; total (optional) = sum of all.  tmp: >= cdiv(n, 2048) ints.
+hipError_t launch_scan(const int* in, int* out, int n, int* tmp, int* total, hipStream_t st) {
+    const int per = SCAN_BLOCK * SCAN_ITEMS;
+    const int nb = cdiv(n > 0 ? n : 1, per);
+    hipLaunchKernelGGL(scan_phase1, dim3(nb), dim3(SCAN_BLOCK), 0, st, in, n, out, tmp);
+    hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(SCAN_BLOCK), 0, st, tmp, nb, total);
+    hipLaunchKernelGGL(scan_phase3, dim3(nb), dim3(SCAN_BLOCK), 0, st, out, n, tmp);
+    return hipGetLastError();
+}
+
+hipError_t launch_ovf_compact(const int* ovf, int N, int* flag_pos /*[N]*/, int* tmp, int* ovf_centre, int* ovf_src,
+                              int* ovf_cnt, hipStream_t st) {
+    if (N == 0) return hipMemsetAsync(ovf_cnt, 0, sizeof(int), st);
+    hipLaunchKernelGGL(flag_nonneg, dim3(cdiv(N, 256)), dim3(256), 0, st, ovf, N, flag_pos);
+    hipError_t e = launch_scan(flag_pos, flag_pos, N, tmp, ovf_cnt, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ovf_write, dim3(cdiv(N, 256)), dim3(256), 0, st, ovf, flag_pos, N, ovf_centre, ovf_src);
+    return hipGetLastError();
+}
+
+hipError_t launch_rev_build(const int* nbr, int N, int K, int S, const int* ovf_src, const int* ovf_cnt,
+                            int* rev_ptr /*[N+1]*/, int* cursor /*[N]*/, int* tmp, int* rev_rows, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)N, st);
+    if (e != hipSuccess) return e;
+    const long long rows = (long long)N * S + (ovf_cnt ? N : 0);
+    hipLaunchKernelGGL(rev_count, dim3(cdiv(rows, 256)), dim3(256), 0, st, nbr, N, K, S, ovf_src, ovf_cnt, cursor);
+    e = launch_scan(cursor, rev_ptr, N, tmp, rev_ptr + N, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)N, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rev_fill, dim3(cdiv(rows, 256)), dim3(256), 0, st, nbr, N, K, S, ovf_src, ovf_cnt, rev_ptr, cursor, rev_rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_degree(const int* nbr, const int* ovf, int N, int K, int* deg, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(table_degree, dim3(cdiv(N, 256)), dim3(256), 0, st, nbr, ovf, N, K, deg);
+    return hipGetLastError();
+}
+hipError_t launch_table_to_edges(const int* nbr, const int* ovf, int N, int K, const int* off, long long E,
+                                 long long* edge_index, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(table_to_edges, dim3(cdiv(N, 256)), dim3(256), 0, st, nbr, ovf, N, K, off, E, edge_index);
+    return hipGetLastError();
+}
+hipError_t launch_edges_to_table(const long long* edge_index, long long E, int N, int K, int* first /*[N]*/,
+                                 int* nbr, int* ovf, int* err, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(nbr, 0xff, sizeof(int) * (size_t)N * K, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ovf, 0xff, sizeof(int) * (size_t)N, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(err, 0, sizeof(int), st);
+    if (e != hipSuccess || E == 0) return e;
+    hipLaunchKernelGGL(edges_first, dim3(cdiv(E, 256)), dim3(256), 0, st, edge_index + E, E, first);
+    hipLaunchKernelGGL(edges_to_table, dim3(cdiv(E, 256)), dim3(256), 0, st, edge_index, edge_index + E, E, first, K, nbr, ovf, err);
+    return hipGetLastError();
+}
+
+hipError_t launch_globals(const float* x, long long ldx, int F, const int* ptr, int B, const int* nbr, const int* ovf,
+                          int K, const int* n_pulses, float* out, hipStream_t st) {
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(globals_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, ldx, F, ptr, B, nbr, ovf, K, n_pulses, out);
+    return hipGetLastError();
+}
+hipError_t launch_concat_globals(const float* x, long long ldx, int F, const float* gv, int G, const int* batch, int N,
+                                 float* x0, int ld0, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(concat_globals, dim3(cdiv((long long)N * ld0, 256)), dim3(256), 0, st, x, ldx, F, gv, G, batch, N, x0, ld0);
+    return hipGetLastError();
+}
+hipError_t launch_ptr_to_batch(const int* ptr, int B, int* batch, hipStream_t st) {
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(ptr_to_batch, dim3(B), dim3(256), 0, st, ptr, B, batch);
+    return hipGetLastError();
+}
+
+}  // namespace gn

@@ -1,0 +1,52 @@
+// graphnet_amd/csrc/launchers.hpp — host launcher prototypes shared with the C ABI (cabi.hip).
+#pragma once
+#include "common.hpp"
+
+namespace gn {
+// graph.hip
+hipError_t launch_knn(const float* x, long long ldx, const int* cols, int D, const int* batch, const int* ptr,
+                      int N, int k, int strict, int* nbr, int* ovf, hipStream_t st);
+hipError_t launch_scan(const int* in, int* out, int n, int* tmp, int* total, hipStream_t st);
+hipError_t launch_ovf_compact(const int* ovf, int N, int* flag_pos, int* tmp, int* ovf_centre, int* ovf_src,
+                              int* ovf_cnt, hipStream_t st);
+hipError_t launch_rev_build(const int* nbr, int N, int K, int S, const int* ovf_src, const int* ovf_cnt,
+                            int* rev_ptr, int* cursor, int* tmp, int* rev_rows, hipStream_t st);
+hipError_t launch_table_degree(const int* nbr, const int* ovf, int N, int K, int* deg, hipStream_t st);
+hipError_t launch_table_to_edges(const int* nbr, const int* ovf, int N, int K, const int* off, long long E,
+                                 long long* edge_index, hipStream_t st);
+hipError_t launch_edges_to_table(const long long* edge_index, long long E, int N, int K, int* first, int* nbr,
+                                 int* ovf, int* err, hipStream_t st);
+hipError_t launch_globals(const float* x, long long ldx, int F, const int* ptr, int B, const int* nbr, const int* ovf,
+                          int K, const int* n_pulses, float* out, hipStream_t st);
+hipError_t launch_concat_globals(const float* x, long long ldx, int F, const float* gv, int G, const int* batch, int N,
+                                 float* x0, int ld0, hipStream_t st);
+hipError_t launch_ptr_to_batch(const int* ptr, int B, int* batch, hipStream_t st);
+// gemm.hip
+hipError_t launch_gemm_nt(int mode, const Segs& a, int M, const void* Wp, int Kp, int Npad, int Nreal, const Epi& epi,
+                          void* C, long long ldc, int out_lowp, hipStream_t st);
+int gemm_tn_splits(int M);
+hipError_t launch_gemm_tn(int mode, const float* dY, long long lddy, int N1, const Segs& x, int M, float* slab,
+                          float* dW, int accum, hipStream_t st);
+int colsum_blocks(int M);
+hipError_t launch_colsum(const float* X, long long ld, int M, int C, float* part, float* out, int accum, hipStream_t st);
+hipError_t launch_reduce_slabs(const float* slab, int nslab, long long count, float* out, int accum, hipStream_t st);
+// edgeconv.hip
+int edge_slots(int K);
+long long edge_dw2_splits(long long rows);
+hipError_t launch_edge_fwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2,
+                           int H2, float* out, long long ldo, unsigned int* maskbits, hipStream_t st);
+hipError_t launch_edge_bwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H2, const float* gout,
+                           long long ldg, const unsigned int* maskbits, const void* W2Tp, int H2p, void* dpre,
+                           float* dP, long long ldp, hipStream_t st);
+hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
+                           long long ldg, const unsigned int* maskbits, float* slab, float* db2_part, int splits,
+                           hipStream_t st);
+hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows, int N,
+                            float* dQ, long long ldq, hipStream_t st);
+// pool.hip
+hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr, int B, const int* codes, int ns,
+                           float* out, int* argmin, int* argmax, hipStream_t st);
+hipError_t launch_pool_bwd(const float* gout, int C, const int* ptr, const int* batch, int N, const int* codes, int ns,
+                           const int* argmin, const int* argmax, const float* gate, long long ldgate, float* dx,
+                           long long lddx, hipStream_t st);
+}  // namespace gn

@@ -1,0 +1,100 @@
+// graphnet_amd/csrc/pool.hip — graph-level pooling over the batched-CSR layout.
+//
+// Replaces the four torch_scatter passes of models/gnn/dynedge.py:251-264
+// (scatter_min / scatter_max / scatter_sum / scatter_mean over `batch`) by one read of
+// x[N,C]: one workgroup per event, one column per thread, nodes streamed in order
+// (coalesced rows, no atomics, first-occurrence arg for min/max, empty segment -> 0).
+// HBM-bound: algorithmic bytes = N*C*4 read + B*ns*C*4 written.
+#include "common.hpp"
+
+namespace gn {
+
+// scheme codes: 0 = min, 1 = max, 2 = sum, 3 = mean   (order given by the caller)
+struct PoolSchemes { int code[4]; int n; };
+
+__global__ __launch_bounds__(256) void segment_pool_fwd_kernel(
+    const float* __restrict__ x, long long ldx, int C, const int* __restrict__ ptr, int B,
+    PoolSchemes sch, float* __restrict__ out /*[B, n*C]*/, int* __restrict__ argmin, int* __restrict__ argmax)
+{
+    const int g = blockIdx.x;
+    const int lo = ptr[g], hi = ptr[g + 1];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mn = 0.0f, mx = 0.0f, sm = 0.0f;
+        int amn = -1, amx = -1;
+        if (hi > lo) {
+            mn = mx = sm = x[(long long)lo * ldx + c];
+            amn = amx = lo;
+            for (int i = lo + 1; i < hi; ++i) {
+                const float v = x[(long long)i * ldx + c];
+                sm += v;
+                if (v < mn) { mn = v; amn = i; }
+                if (v > mx) { mx = v; amx = i; }
+            }
+        }
+        const float mean = sm / (float)max(hi - lo, 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < sch.n) {
+                const int code = sch.code[s];
+                const float v = code == 0 ? mn : (code == 1 ? mx : (code == 2 ? sm : mean));
+                out[((long long)g * sch.n + s) * C + c] = v;
+            }
+        }
+        if (argmin) argmin[(long long)g * C + c] = amn;
+        if (argmax) argmax[(long long)g * C + c] = amx;
+    }
+}
+
+// dx[i][c] = gate(i,c) * ( g_sum + g_mean / n + [i == argmin] g_min + [i == argmax] g_max )
+__global__ __launch_bounds__(256) void segment_pool_bwd_kernel(
+    const float* __restrict__ gout /*[B, n*C]*/, int C, const int* __restrict__ ptr, const int* __restrict__ batch,
+    int N, PoolSchemes sch, const int* __restrict__ argmin, const int* __restrict__ argmax,
+    const float* __restrict__ gate, long long ldgate, float* __restrict__ dx, long long lddx)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(t / C), c = (int)(t % C);
+    if (i >= N) return;
+    const int g = batch[i];
+    const float n = (float)max(ptr[g + 1] - ptr[g], 1);
+    float v = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s < sch.n) {
+            const float go = gout[((long long)g * sch.n + s) * C + c];
+            const int code = sch.code[s];
+            if (code == 2) v += go;
+            else if (code == 3) v += go / n;
+            else if (code == 0) { if (argmin[(long long)g * C + c] == i) v += go; }
+            else { if (argmax[(long long)g * C + c] == i) v += go; }
+        }
+    }
+    if (gate && !(gate[(long long)i * ldgate + c] > 0.0f)) v = 0.0f;
+    dx[(long long)i * lddx + c] = v;
+}
+
+hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr, int B, const int* codes, int ns,
+                           float* out, int* argmin, int* argmax, hipStream_t st) {
+    if (B == 0) return hipSuccess;
+    if (ns < 1 || ns > 4) return hipErrorInvalidValue;
+    PoolSchemes s;
+    s.n = ns;
+    for (int i = 0; i < 4; ++i) s.code[i] = i < ns ? codes[i] : 0;
+    hipLaunchKernelGGL(segment_pool_fwd_kernel, dim3(B), dim3(256), 0, st, x, ldx, C, ptr, B, s, out, argmin, argmax);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_bwd(const float* gout, int C, const int* ptr, const int* batch, int N, const int* codes, int ns,
+                           const int* argmin, const int* argmax, const float* gate, long long ldgate, float* dx,
+                           long long lddx, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    if (ns < 1 || ns > 4) return hipErrorInvalidValue;
+    PoolSchemes s;
+    s.n = ns;
+    for (int i = 0; i < 4; ++i) s.code[i] = i < ns ? codes[i] : 0;
+    const long long total = (long long)N * C;
+    hipLaunchKernelGGL(segment_pool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gout, C, ptr,
+                       batch, N, s, argmin, argmax, gate, ldgate, dx, lddx);
+    return hipGetLastError();
+}
+
+}  // namespace gn

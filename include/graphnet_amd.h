@@ -1,0 +1,135 @@
+/*
+ * include/graphnet_amd.h — C ABI of libgraphnet_amd.so (hand-written gfx950 HIP kernels).
+ *
+ * Drop-in boundary for the DynEdge message-passing path of graphnet.  The reference has no
+ * FFI of its own (pure Python): its plugin boundary is the Python class
+ * GNN (src/graphnet/models/gnn/gnn.py:11-35) and the third-party operators it calls.
+ * Each entry point below names the reference call site / third-party operator it replaces.
+ * Host-side binding: graphnet_amd/_lib.py (ctypes); see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the comment says "host";
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued, nothing synchronises;
+ *   - return value: 0 on success, otherwise a hipError_t code; gn_last_error() has the text;
+ *   - mode: 0 = f32 operands (v_mfma_f32_32x32x2_f32, parity mode), 1 = bf16 operands
+ *     (v_mfma_f32_32x32x16_bf16); accumulation is fp32 in both; "T" below is float or bf16;
+ *   - layout: batched CSR — x[N, ld] row-major fp32, ptr[B+1] int32 event offsets,
+ *     batch[N] int32 event ids, neighbour table nbr[N, K] int32 (-1 padded) + overflow list.
+ */
+#ifndef GRAPHNET_AMD_H
+#define GRAPHNET_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GN_MODE_F32 0
+#define GN_MODE_BF16 1
+#define GN_MAXSEG 6
+
+const char* gn_last_error(void);
+int gn_abi_version(void);
+
+/* ---- graph construction ------------------------------------------------------------- */
+
+/* torch_geometric.nn.knn_graph(x[:, cols], k, batch) as called at
+ * models/graphs/edges/edges.py:74-78 and models/components/layers.py:63-67.
+ * cols: HOST int[D] (D <= 8).  strict = 0: k+1-with-self then mask (degree k or k+1, the extra
+ * neighbour goes to ovf[N], -1 if none); strict = 1: self excluded, ovf may be NULL. */
+int gn_knn_graph(const float* x, int64_t ldx, const int32_t* cols_host, int32_t D,
+                 const int32_t* batch, const int32_t* ptr, int32_t N, int32_t k, int32_t strict,
+                 int32_t* nbr, int32_t* ovf, void* stream);
+
+/* exclusive scan; tmp: >= gn_scan_tmp_ints(n) ints; total (optional) receives the sum */
+int64_t gn_scan_tmp_ints(int64_t n);
+int gn_scan_i32(const int32_t* in, int32_t* out, int32_t n, int32_t* tmp, int32_t* total, void* stream);
+
+/* compact ovf[N] (>=0 entries) into ascending (ovf_centre, ovf_src) lists + device count */
+int gn_ovf_compact(const int32_t* ovf, int32_t N, int32_t* work_N, int32_t* tmp,
+                   int32_t* ovf_centre, int32_t* ovf_src, int32_t* ovf_cnt, void* stream);
+
+/* reverse adjacency of the edge rows (row = i*S+slot, or N*S+t for overflow row t),
+ * S = gn_edge_slots(K).  rev_ptr[N+1], cursor[N] scratch, rev_rows[>= N*K+N]. */
+int32_t gn_edge_slots(int32_t K);
+int gn_rev_build(const int32_t* nbr, int32_t N, int32_t K, const int32_t* ovf_src, const int32_t* ovf_cnt,
+                 int32_t* rev_ptr, int32_t* cursor, int32_t* tmp, int32_t* rev_rows, void* stream);
+
+/* table <-> PyG edge_index[2,E] int64 (row 0 = source j, row 1 = target i, grouped by i) */
+int gn_table_degree(const int32_t* nbr, const int32_t* ovf, int32_t N, int32_t K, int32_t* deg, void* stream);
+int gn_table_to_edge_index(const int32_t* nbr, const int32_t* ovf, int32_t N, int32_t K, const int32_t* off,
+                           int64_t E, int64_t* edge_index, void* stream);
+int gn_edge_index_to_table(const int64_t* edge_index, int64_t E, int32_t N, int32_t K, int32_t* first_N,
+                           int32_t* nbr, int32_t* ovf, int32_t* err, void* stream);
+
+int gn_ptr_to_batch(const int32_t* ptr, int32_t B, int32_t* batch, void* stream);
+
+/* DynEdge._calculate_global_variables (models/gnn/dynedge.py:266-293; homophily:
+ * models/utils.py:13-29): out[B, F+5] = [mean_F | h_x h_y h_z h_t | log10 n_pulses] */
+int gn_graph_globals(const float* x, int64_t ldx, int32_t F, const int32_t* ptr, int32_t B,
+                     const int32_t* nbr, const int32_t* ovf, int32_t K, const int32_t* n_pulses,
+                     float* out, void* stream);
+/* "distribute" + cat (dynedge.py:308-319) as a gather: x0[i] = [x[i] | gv[batch[i]] | 0-pad to ld0] */
+int gn_concat_globals(const float* x, int64_t ldx, int32_t F, const float* gv, int32_t G,
+                      const int32_t* batch, int32_t N, float* x0, int32_t ld0, void* stream);
+
+/* ---- dense per-node layers (torch.nn.Linear at dynedge.py:198-231) -------------------- */
+
+/* C[M, Nreal] = epi(sum_s A_s[M, width_s] . Wp[:, seg s]^T + bias); Wp: T[Npad][Kp] packed so
+ * that segment s occupies kpad_s (multiple of 32) columns; A_s fp32 with row pitch ld_s.
+ * a_ptr/a_ld/a_width/a_kpad: HOST arrays of nseg entries.  gate: output *= (gate[m,n] > 0).
+ * out_lowp: C is T instead of fp32 (bf16 mode only). */
+int gn_linear_fwd(int32_t mode, int32_t nseg, const float* const* a_ptr, const int64_t* a_ld,
+                  const int32_t* a_width, const int32_t* a_kpad, int32_t M,
+                  const void* Wp, int32_t Kp, int32_t Npad, int32_t Nreal,
+                  const float* bias, const float* gate, int64_t ldgate, int32_t relu, int32_t accum,
+                  void* C, int64_t ldc, int32_t out_lowp, void* stream);
+
+/* dW[N1, sum width_s] (+)= dY[M,N1]^T . [X_0 | X_1 | ...]; slab: >= gn_linear_wgrad_splits(M)*N1*Ktot floats */
+int32_t gn_linear_wgrad_splits(int32_t M);
+int gn_linear_wgrad(int32_t mode, const float* dY, int64_t lddy, int32_t N1, int32_t nseg,
+                    const float* const* x_ptr, const int64_t* x_ld, const int32_t* x_width, int32_t M,
+                    float* slab, float* dW, int32_t accum, void* stream);
+
+/* out[C] (+)= column sums of X[M, C]; part: >= gn_colsum_blocks(M)*C floats */
+int32_t gn_colsum_blocks(int32_t M);
+int gn_colsum(const float* X, int64_t ld, int32_t M, int32_t C, float* part, float* out, int32_t accum, void* stream);
+int gn_reduce_slabs(const float* slab, int32_t nslab, int64_t count, float* out, int32_t accum, void* stream);
+
+/* ---- fused EdgeConv (torch_geometric.nn.EdgeConv via DynEdgeConv, layers.py:55-60) ---- */
+
+/* out[i, :H2] = sum_slots relu(relu(P[i]+Q[j]) . W2^T + b2); PQ: T[N, 2*H1p]; W2p: T[ceil128(H2)][H1p];
+ * maskbits: uint32[(N*S + N) * ceil(H2/32)] (relu bits for backward). */
+int gn_edgeconv_fwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
+                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p,
+                    const void* W2p, const float* b2, int32_t H2, float* out, int64_t ldo,
+                    uint32_t* maskbits, void* stream);
+/* dP[N,H1p] (fp32, pitch ldp) and dpre rows T[(N*S+N), H1p]; W2Tp: T[ceil128(H1p)][H2p] */
+int gn_edgeconv_bwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
+                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H2,
+                    const float* gout, int64_t ldg, const uint32_t* maskbits, const void* W2Tp, int32_t H2p,
+                    void* dpre, float* dP, int64_t ldp, void* stream);
+/* slab[splits][H2][H1] and db2_part[splits][H2] partials (reduce with gn_reduce_slabs) */
+int32_t gn_edgeconv_dw2_splits(int64_t rows);
+int gn_edgeconv_dw2(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
+                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H1,
+                    int32_t H2, const float* gout, int64_t ldg, const uint32_t* maskbits,
+                    float* slab, float* db2_part, int32_t splits, void* stream);
+/* dQ[j] = sum of dpre rows that gathered from j (ascending row id) */
+int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int32_t* rev_ptr,
+                          const int32_t* rev_rows, int32_t N, float* dQ, int64_t ldq, void* stream);
+
+/* ---- pooling (torch_scatter.scatter_{min,max,sum,mean}, dynedge.py:251-264) ------------ */
+/* codes: HOST int[ns], 0 = min, 1 = max, 2 = sum, 3 = mean; out[B, ns*C] */
+int gn_segment_pool_fwd(const float* x, int64_t ldx, int32_t C, const int32_t* ptr, int32_t B,
+                        const int32_t* codes_host, int32_t ns, float* out, int32_t* argmin, int32_t* argmax,
+                        void* stream);
+int gn_segment_pool_bwd(const float* gout, int32_t C, const int32_t* ptr, const int32_t* batch, int32_t N,
+                        const int32_t* codes_host, int32_t ns, const int32_t* argmin, const int32_t* argmax,
+                        const float* gate, int64_t ldgate, float* dx, int64_t lddx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHNET_AMD_H */

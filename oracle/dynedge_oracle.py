@@ -1,0 +1,418 @@
+"""oracle/dynedge_oracle.py — plain-torch CPU restatement of the reference DynEdge path.
+
+TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module; nothing under
+``graphnet_amd/`` does (the product path fails loudly without its HIP library).
+
+PARITY UNPINNED: the reference delegates every arithmetic step of this
+path to wheels that are neither vendored under /root/reference nor installed in this
+image — torch-geometric >= 2.3 (``EdgeConv``, ``knn_graph``, ``homophily``),
+torch-cluster >= 1.6 (``knn``), torch-scatter >= 2.0 (``scatter_*``); pins in the
+reference's ``setup.py:52-59``.  ``import graphnet`` raises ModuleNotFoundError here, and the
+reference's own tests hold no golden vector for DynEdge outputs.  What *is* pinned:
+  * the selection/ordering code against ``tests/models/test_minkowski.py:12-160``
+    (distance matrices + 4-node k=2 edge list)           -> tests/test_oracle_pins.py
+  * LogCosh against ``tests/training/test_loss_functions.py:40-63``
+  * parameter names/shapes against SURVEY.md Appendix B (reference ``dynedge.py:183-249``).
+Everything else is this file's restatement of the published third-party behaviour.
+
+Each function cites the reference file:line it follows (paths relative to
+/root/reference/src/graphnet/).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+from torch import Tensor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/knn_oracle.c with gcc (recipe: oracle/Makefile)."""
+    so = os.path.join(_HERE, "libgn_oracle.so")
+    src = os.path.join(_HERE, "knn_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libgn_oracle.so"])
+    return so
+
+
+def _lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.gn_oracle_knn_graph.restype = ctypes.c_int64
+        _LIB.gn_oracle_minkowski_knn.restype = ctypes.c_int64
+    return _LIB
+
+
+# --------------------------------------------------------------------------------------
+# k-NN graph  (models/graphs/edges/edges.py:72-80 ; models/components/layers.py:63-67)
+# --------------------------------------------------------------------------------------
+def _cols_of(subset: Union[slice, Sequence[int], None], width: int) -> List[int]:
+    if subset is None:
+        return list(range(width))
+    if isinstance(subset, slice):
+        return list(range(width))[subset]
+    return [int(c) for c in subset]
+
+
+def batch_to_ptr(batch: Tensor, num_graphs: Optional[int] = None) -> Tensor:
+    if num_graphs is None:
+        num_graphs = int(batch.max()) + 1 if batch.numel() else 0
+    counts = torch.bincount(batch, minlength=num_graphs)
+    ptr = torch.zeros(num_graphs + 1, dtype=torch.int64)
+    ptr[1:] = torch.cumsum(counts, 0)
+    return ptr
+
+
+def knn_table(
+    x: Tensor,
+    k: int,
+    ptr: Tensor,
+    cols: Union[slice, Sequence[int], None] = None,
+    mode: str = "compat",
+) -> Tuple[Tensor, Tensor]:
+    """Neighbour table ``nbr[N, k+1]`` (int32, -1 padded) and ``deg[N]`` via the C oracle."""
+    x = x.detach().to(torch.float32).contiguous()
+    n, ld = x.shape
+    c = np.asarray(_cols_of(cols, ld), dtype=np.int32)
+    p = ptr.to(torch.int64).contiguous().numpy()
+    nbr = np.empty((n, k + 1), dtype=np.int32)
+    deg = np.empty((n,), dtype=np.int32)
+    xn = x.numpy()
+    rc = _lib().gn_oracle_knn_graph(
+        xn.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(ld),
+        c.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(len(c)),
+        p.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(len(p) - 1),
+        ctypes.c_int32(k), ctypes.c_int32(0 if mode == "compat" else 1),
+        nbr.ctypes.data_as(ctypes.c_void_p), deg.ctypes.data_as(ctypes.c_void_p),
+    )
+    if rc < 0:
+        raise ValueError("gn_oracle_knn_graph: bad arguments")
+    return torch.from_numpy(nbr), torch.from_numpy(deg)
+
+
+def table_to_edge_index(nbr: Tensor) -> Tensor:
+    """``edge_index[0] = j`` (source), ``edge_index[1] = i`` (target), grouped by i."""
+    n, w = nbr.shape
+    centre = torch.arange(n, dtype=torch.int64).unsqueeze(1).expand(n, w)
+    valid = nbr >= 0
+    return torch.stack([nbr[valid].to(torch.int64), centre[valid]], dim=0)
+
+
+def knn_graph(
+    x: Tensor,
+    k: int,
+    batch: Optional[Tensor] = None,
+    cols: Union[slice, Sequence[int], None] = None,
+    mode: str = "compat",
+) -> Tensor:
+    """Restates ``torch_geometric.nn.knn_graph(x[:, cols], k, batch)`` (loop=False)."""
+    if batch is None:
+        ptr = torch.tensor([0, x.shape[0]], dtype=torch.int64)
+    else:
+        ptr = batch_to_ptr(batch)
+    nbr, _ = knn_table(x, k, ptr, cols, mode)
+    return table_to_edge_index(nbr)
+
+
+def knn_graph_py(x: np.ndarray, k: int, ptr: Sequence[int], mode: str = "compat") -> np.ndarray:
+    """Pure-Python/numpy restatement (tiny cases only) used to cross-check the C oracle."""
+    x = np.asarray(x, dtype=np.float32)
+    src, dst = [], []
+    kk = k + 1 if mode == "compat" else k
+    for b in range(len(ptr) - 1):
+        lo, hi = int(ptr[b]), int(ptr[b + 1])
+        for i in range(lo, hi):
+            cand = []
+            for j in range(lo, hi):
+                if mode != "compat" and j == i:
+                    continue
+                d2 = np.float32(0.0)
+                for d in range(x.shape[1]):
+                    diff = np.float32(x[j, d] - x[i, d])
+                    d2 = np.float32(d2 + np.float32(diff * diff))
+                cand.append((float(d2), j))
+            cand.sort(key=lambda t: (t[0], t[1]))
+            for d2, j in cand[:kk]:
+                if j != i and d2 < 1e10:
+                    src.append(j)
+                    dst.append(i)
+    return np.asarray([src, dst], dtype=np.int64)
+
+
+def minkowski_knn(x: Tensor, k: int, c: float, time_like_weight: float = 1.0):
+    """models/graphs/edges/minkowski.py:12-81 restated on the oracle's selection code."""
+    x = x.detach().to(torch.float32).contiguous()
+    n, ld = x.shape
+    src = np.empty((n * k,), dtype=np.int64)
+    dst = np.empty((n * k,), dtype=np.int64)
+    dist = np.empty((n, n), dtype=np.float32)
+    e = _lib().gn_oracle_minkowski_knn(
+        x.numpy().ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(ld), ctypes.c_int32(n),
+        ctypes.c_int32(k), ctypes.c_float(c), ctypes.c_float(time_like_weight),
+        src.ctypes.data_as(ctypes.c_void_p), dst.ctypes.data_as(ctypes.c_void_p),
+        dist.ctypes.data_as(ctypes.c_void_p),
+    )
+    return np.stack([src[:e], dst[:e]]), dist
+
+
+def minkowski_distance_mat(x: np.ndarray, y: np.ndarray, c: float) -> np.ndarray:
+    """models/graphs/edges/minkowski.py:12-35 (numpy restatement)."""
+    d = x[:, None, :] - y[None, :, :]
+    return (d[:, :, :3] ** 2).sum(-1) - (d[:, :, 3] * c) ** 2
+
+
+# --------------------------------------------------------------------------------------
+# torch_scatter restatements (dynedge.py:13-18, 251-264, 278)
+# --------------------------------------------------------------------------------------
+def scatter_sum(src: Tensor, index: Tensor, dim_size: int) -> Tensor:
+    out = torch.zeros((dim_size,) + src.shape[1:], dtype=src.dtype)
+    return out.index_add_(0, index, src)
+
+
+def scatter_mean(src: Tensor, index: Tensor, dim_size: int) -> Tensor:
+    s = scatter_sum(src, index, dim_size)
+    cnt = torch.bincount(index, minlength=dim_size).clamp(min=1).to(src.dtype)
+    return s / cnt.view((-1,) + (1,) * (src.dim() - 1))
+
+
+def _scatter_minmax(src: Tensor, index: Tensor, dim_size: int, op: str) -> Tensor:
+    idx = index.view((-1,) + (1,) * (src.dim() - 1)).expand_as(src)
+    out = torch.zeros((dim_size,) + src.shape[1:], dtype=src.dtype)
+    # empty segments stay 0 (torch_scatter fills them with 0 after the reduction)
+    return out.scatter_reduce(0, idx, src, reduce=op, include_self=False)
+
+
+def scatter_min(src: Tensor, index: Tensor, dim_size: int) -> Tensor:
+    return _scatter_minmax(src, index, dim_size, "amin")
+
+
+def scatter_max(src: Tensor, index: Tensor, dim_size: int) -> Tensor:
+    return _scatter_minmax(src, index, dim_size, "amax")
+
+
+GLOBAL_POOLINGS = {"min": scatter_min, "max": scatter_max, "sum": scatter_sum, "mean": scatter_mean}
+
+
+# --------------------------------------------------------------------------------------
+# homophily (models/utils.py:13-29 -> torch_geometric.utils.homophily, method="edge")
+# --------------------------------------------------------------------------------------
+def homophily(edge_index: Tensor, y: Tensor, batch: Tensor, num_graphs: int) -> Tensor:
+    row, col = edge_index[0], edge_index[1]
+    out = torch.zeros(row.shape[0], dtype=torch.float32)
+    out[y[row] == y[col]] = 1.0
+    return scatter_mean(out, batch[col], num_graphs)
+
+
+def calculate_xyzt_homophily(x: Tensor, edge_index: Tensor, batch: Tensor, num_graphs: int):
+    return tuple(homophily(edge_index, x[:, c], batch, num_graphs).reshape(-1, 1) for c in range(4))
+
+
+# --------------------------------------------------------------------------------------
+# EdgeConv (models/components/layers.py:55-60 -> torch_geometric.nn.EdgeConv)
+# --------------------------------------------------------------------------------------
+def edge_conv(x: Tensor, edge_index: Tensor, nn: torch.nn.Module, aggr: str = "add") -> Tensor:
+    x_i = x.index_select(0, edge_index[1])
+    x_j = x.index_select(0, edge_index[0])
+    msg = nn(torch.cat([x_i, x_j - x_i], dim=-1))
+    n = x.shape[0]
+    if aggr == "add":
+        return scatter_sum(msg, edge_index[1], n)
+    if aggr == "mean":
+        return scatter_mean(msg, edge_index[1], n)
+    if aggr == "max":
+        return scatter_max(msg, edge_index[1], n)
+    raise ValueError(aggr)
+
+
+class _ConvHolder(torch.nn.Module):
+    """Gives the conv MLP the attribute name ``nn`` so state-dict keys match
+    ``_conv_layers.{l}.nn.{idx}.*`` (dynedge.py:193-211)."""
+
+    def __init__(self, mlp: torch.nn.Sequential):
+        super().__init__()
+        self.nn = mlp
+
+
+class DynEdgeOracle(torch.nn.Module):
+    """CPU restatement of ``models/gnn/dynedge.py`` (ctor l.24-181, layers l.183-249,
+    forward l.295-349).  Parameter names and shapes equal the reference's."""
+
+    def __init__(
+        self,
+        nb_inputs: int,
+        *,
+        nb_neighbours: int = 8,
+        features_subset: Optional[Union[List[int], slice]] = None,
+        dynedge_layer_sizes: Optional[List[Tuple[int, ...]]] = None,
+        post_processing_layer_sizes: Optional[List[int]] = None,
+        readout_layer_sizes: Optional[List[int]] = None,
+        global_pooling_schemes: Optional[Union[str, List[str]]] = None,
+        add_global_variables_after_pooling: bool = False,
+        activation_layer: Optional[str] = None,
+        add_norm_layer: bool = False,
+        skip_readout: bool = False,
+        knn_mode: str = "compat",
+        literal_distribute: bool = False,
+    ):
+        super().__init__()
+        if features_subset is None:
+            features_subset = slice(0, 3)
+        if dynedge_layer_sizes is None:
+            dynedge_layer_sizes = [(128, 256), (336, 256), (336, 256), (336, 256)]
+        if post_processing_layer_sizes is None:
+            post_processing_layer_sizes = [336, 256]
+        if readout_layer_sizes is None:
+            readout_layer_sizes = [128]
+        if isinstance(global_pooling_schemes, str):
+            global_pooling_schemes = [global_pooling_schemes]
+        if global_pooling_schemes is not None:
+            for s in global_pooling_schemes:
+                assert s in GLOBAL_POOLINGS
+        if add_global_variables_after_pooling:
+            assert global_pooling_schemes
+        if activation_layer is None or activation_layer.lower() == "relu":
+            act: torch.nn.Module = torch.nn.ReLU()
+        elif activation_layer.lower() == "gelu":
+            act = torch.nn.GELU()
+        else:
+            raise ValueError(f"Activation layer {activation_layer} not supported.")
+        self._activation = act
+        self._nb_inputs = nb_inputs
+        self._nb_outputs = readout_layer_sizes[-1]
+        self._nb_global_variables = 5 + nb_inputs
+        self._nb_neighbours = nb_neighbours
+        self._features_subset = features_subset
+        self._pools = global_pooling_schemes
+        self._after = add_global_variables_after_pooling
+        self._skip_readout = skip_readout
+        self._knn_mode = knn_mode
+        self._literal_distribute = literal_distribute
+
+        nb_in_feat = nb_inputs + (0 if self._after else self._nb_global_variables)
+        self._conv_layers = torch.nn.ModuleList()
+        nb_latent = nb_in_feat
+        nb_out = nb_latent
+        for sizes in dynedge_layer_sizes:
+            layers: List[torch.nn.Module] = []
+            ls = [nb_latent] + list(sizes)
+            for ix, (nb_in, nb_out) in enumerate(zip(ls[:-1], ls[1:])):
+                if ix == 0:
+                    nb_in *= 2
+                layers.append(torch.nn.Linear(nb_in, nb_out))
+                if add_norm_layer:
+                    layers.append(torch.nn.LayerNorm(nb_out))
+                layers.append(act)
+            self._conv_layers.append(_ConvHolder(torch.nn.Sequential(*layers)))
+            nb_latent = nb_out
+        nb_latent = sum(s[-1] for s in dynedge_layer_sizes) + nb_in_feat
+        post: List[torch.nn.Module] = []
+        ls = [nb_latent] + list(post_processing_layer_sizes)
+        for nb_in, nb_out in zip(ls[:-1], ls[1:]):
+            post.append(torch.nn.Linear(nb_in, nb_out))
+            if add_norm_layer:
+                post.append(torch.nn.LayerNorm(nb_out))
+            post.append(act)
+        self._post_processing = torch.nn.Sequential(*post)
+        nb_pool = len(self._pools) if self._pools else 1
+        nb_latent = nb_out * nb_pool + (self._nb_global_variables if self._after else 0)
+        ro: List[torch.nn.Module] = []
+        ls = [nb_latent] + list(readout_layer_sizes)
+        for nb_in, nb_out in zip(ls[:-1], ls[1:]):
+            ro.append(torch.nn.Linear(nb_in, nb_out))
+            ro.append(act)
+        self._readout = torch.nn.Sequential(*ro)
+
+    # dynedge.py:266-293
+    def global_variables(self, x, edge_index, batch, n_pulses, num_graphs):
+        hx, hy, hz, ht = calculate_xyzt_homophily(x, edge_index, batch, num_graphs)
+        means = scatter_mean(x, batch, num_graphs)
+        logn = torch.log10(n_pulses).to(torch.float32).unsqueeze(1)
+        return torch.cat([means, hx, hy, hz, ht, logn], dim=1)
+
+    def forward(self, x: Tensor, edge_index: Tensor, batch: Tensor, n_pulses: Tensor,
+                return_trace: bool = False):
+        num_graphs = int(n_pulses.shape[0])
+        trace = {}
+        gv = self.global_variables(x, edge_index, batch, n_pulses, num_graphs)
+        trace["global_variables"] = gv
+        if not self._after:
+            if self._literal_distribute:  # dynedge.py:308-317, literally
+                distribute = (batch.unsqueeze(1) == torch.unique(batch).unsqueeze(0)).float()
+                gvd = torch.sum(distribute.unsqueeze(2) * gv.unsqueeze(0), dim=1)
+            else:  # identical for finite inputs
+                gvd = gv[batch]
+            x = torch.cat((x, gvd), dim=1)
+        skips = [x]
+        trace["edge_index"] = [edge_index]
+        for conv in self._conv_layers:
+            x = edge_conv(x, edge_index, conv.nn, "add")
+            edge_index = knn_graph(x, self._nb_neighbours, batch, self._features_subset,
+                                   self._knn_mode)
+            skips.append(x)
+            trace["edge_index"].append(edge_index)
+        trace["conv_out"] = skips
+        x = torch.cat(skips, dim=1)
+        x = self._post_processing(x)
+        trace["post"] = x
+        if not self._skip_readout:
+            if self._pools:
+                x = torch.cat([GLOBAL_POOLINGS[s](x, batch, num_graphs) for s in self._pools], 1)
+                trace["pooled"] = x
+                if self._after:
+                    x = torch.cat([x, gv], dim=1)
+            x = self._readout(x)
+        return (x, trace) if return_trace else x
+
+
+# --------------------------------------------------------------------------------------
+# Task head + loss (models/task/task.py:272-337, task/reconstruction.py:101-112,
+# training/loss_functions.py:34-60,93-112, utilities/maths.py:6-8)
+# --------------------------------------------------------------------------------------
+def energy_reconstruction(latent: Tensor, affine: torch.nn.Linear, log10_transform: bool = True):
+    z = affine(latent)
+    e = torch.nn.functional.softplus(z, beta=0.05) + torch.finfo(z.dtype).eps
+    return torch.log10(e) if log10_transform else e
+
+
+def log_cosh_elements(prediction: Tensor, target: Tensor) -> Tensor:
+    diff = prediction - target
+    return diff + torch.nn.functional.softplus(-2.0 * diff) - math.log(2.0)
+
+
+def log_cosh_loss(prediction: Tensor, target: Tensor, weights: Optional[Tensor] = None) -> Tensor:
+    el = log_cosh_elements(prediction, target)
+    if weights is not None:
+        el = el * weights
+    return el.mean()
+
+
+def piecewise_linear_factor(step: int, milestones: Sequence[int], factors: Sequence[float]) -> float:
+    """training/callbacks.py:65-78."""
+    return float(np.interp(step, milestones, factors))
+
+
+class StandardModelOracle(torch.nn.Module):
+    """DynEdge + EnergyReconstruction + LogCosh (standard_model.py:71-119) on CPU."""
+
+    def __init__(self, nb_inputs: int = 7, **dynedge_kwargs):
+        super().__init__()
+        self.backbone = DynEdgeOracle(nb_inputs, **dynedge_kwargs)
+        self._affine = torch.nn.Linear(self.backbone._nb_outputs, 1)
+
+    def forward(self, x, edge_index, batch, n_pulses):
+        latent = self.backbone(x, edge_index, batch, n_pulses)
+        return energy_reconstruction(latent, self._affine)
+
+    def loss(self, x, edge_index, batch, n_pulses, energy):
+        pred = self.forward(x, edge_index, batch, n_pulses)
+        return log_cosh_loss(pred, torch.log10(energy).unsqueeze(1))

@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz — run HERE (the build container), never on the GPU box.
+
+Step 1 (``inputs``): copies DATA (no source) out of the reference's bundled test files:
+  * /root/reference/data/tests/sqlite/oscNext_genie_level7_v02/*.db          (5 events, FEATURES.ICECUBE86)
+  * /root/reference/data/tests/sqlite/upgrade_genie_step4_*/*.db             (5 events, 14 features)
+  * /root/reference/data/examples/sqlite/prometheus/prometheus-events.db     (50 events, 4 features)
+  * /root/reference/data/geometry_tables/icecube/icecube86.parquet           (5407 sensors)
+  * known answers transcribed from the reference's own tests
+    (tests/models/test_minkowski.py:12-160) -> reference_known_answers.npz
+into raw (un-standardized) float64 pulse arrays + event offsets.
+
+Step 2 (``expected``): runs THIS repo's oracle (oracle/) on those inputs and on seeded
+synthetic batches, and stores the expected outputs the GPU parity tests compare against
+when /root/reference and the C oracle build are not needed (``-m gpu`` on the box still
+re-runs the oracle live; these files pin it across rounds).
+
+The reference itself cannot be imported here (ModuleNotFoundError: pytorch_lightning,
+torch_geometric, torch_scatter, ... — SURVEY.md §8c), so no reference-generated vector
+exists: expected outputs are "parity unpinned" restatement outputs.
+"""
+import os
+import sqlite3
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/data"
+
+ICECUBE86 = ["dom_x", "dom_y", "dom_z", "dom_time", "charge", "rde", "pmt_area"]
+UPGRADE = ICECUBE86 + ["string", "pmt_number", "dom_number", "pmt_dir_x", "pmt_dir_y", "pmt_dir_z", "dom_type"]
+PROMETHEUS = ["sensor_pos_x", "sensor_pos_y", "sensor_pos_z", "t"]
+
+
+def _read_events(db, table, features, truth_table, truth_col):
+    con = sqlite3.connect(f"file:{db}?mode=ro", uri=True)
+    evs = [r[0] for r in con.execute(f"select distinct event_no from {truth_table} order by event_no")]
+    xs, ptr, truth = [], [0], []
+    for ev in evs:
+        rows = con.execute(
+            f"select {', '.join(features)} from {table} where event_no = ? order by rowid", (ev,)
+        ).fetchall()
+        a = np.asarray(rows, dtype=np.float64).reshape(-1, len(features))
+        xs.append(a)
+        ptr.append(ptr[-1] + len(a))
+        truth.append(con.execute(f"select {truth_col} from {truth_table} where event_no = ?", (ev,)).fetchone()[0])
+    return np.concatenate(xs, 0), np.asarray(ptr, np.int64), np.asarray(truth, np.float64), np.asarray(evs, np.int64)
+
+
+def make_inputs():
+    out = {}
+    x, ptr, e, ev = _read_events(
+        f"{REF}/tests/sqlite/oscNext_genie_level7_v02/oscNext_genie_level7_v02_first_5_frames.db",
+        "SRTInIcePulses", ICECUBE86, "truth", "energy")
+    out.update(deepcore_x=x, deepcore_ptr=ptr, deepcore_energy=e, deepcore_event_no=ev)
+    x, ptr, e, ev = _read_events(
+        f"{REF}/tests/sqlite/upgrade_genie_step4_140028_000998_first_5_frames/"
+        "upgrade_genie_step4_140028_000998_first_5_frames.db",
+        "SplitInIcePulses", UPGRADE, "truth", "energy")
+    out.update(upgrade_x=x, upgrade_ptr=ptr, upgrade_energy=e, upgrade_event_no=ev)
+    x, ptr, e, ev = _read_events(
+        f"{REF}/examples/sqlite/prometheus/prometheus-events.db",
+        "total", PROMETHEUS, "mc_truth", "total_energy")
+    out.update(prometheus_x=x, prometheus_ptr=ptr, prometheus_energy=e, prometheus_event_no=ev)
+    np.savez_compressed(os.path.join(HERE, "reference_events.npz"), **out)
+
+    import pyarrow.parquet as pq
+    t = pq.read_table(f"{REF}/geometry_tables/icecube/icecube86.parquet").to_pandas().reset_index(drop=True)
+    geo = np.stack([t[c].to_numpy(np.float64) for c in ["dom_x", "dom_y", "dom_z", "rde", "pmt_area"]], 1)
+    np.savez_compressed(os.path.join(HERE, "icecube86_geometry.npz"),
+                        table=geo.astype(np.float32), string=t["string"].to_numpy(np.int16))
+
+    # Known answers held by the reference's own tests (tests/models/test_minkowski.py).
+    vec1 = np.array([[0, 0, 0, 0], [0, 0, 1, 1], [1, 0, 0, 1], [1, 0, 1, 2]], np.float32)
+    vec2 = np.array([[0, 0, 0, -1], [1, 1, 1, 0]], np.float32)
+    np.savez(os.path.join(HERE, "reference_known_answers.npz"),
+             minkowski_vec1=vec1, minkowski_vec2=vec2,
+             minkowski_expected11=np.array([[0, 0, 0, -2], [0, 0, 2, 0], [0, 2, 0, 0], [-2, 0, 0, 0]], np.float32),
+             minkowski_expected12=np.array([[-1, 3], [-3, 1], [-3, 1], [-7, -3]], np.float32),
+             minkowski_expected22=np.array([[0, 2], [2, 0]], np.float32),
+             minkowski_knn_k2_edge_index=np.array([[1, 2, 0, 3, 0, 3, 1, 2], [0, 0, 1, 1, 2, 2, 3, 3]], np.int64),
+             logcosh_x=np.array([-100, -10, -1, 0, 1, 10, 100], np.float32))
+    print("inputs written")
+
+
+def make_expected():
+    sys.path.insert(0, ROOT)
+    import torch
+    from oracle import dynedge_oracle as orc
+    from graphnet_amd.detector import IceCube86, IceCubeUpgrade, Prometheus
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+
+    ev = np.load(os.path.join(HERE, "reference_events.npz"))
+    out = {}
+    for name, det, names in (("deepcore", IceCube86(), ICECUBE86), ("upgrade", IceCubeUpgrade(), UPGRADE),
+                             ("prometheus", Prometheus(), PROMETHEUS)):
+        x = det(torch.tensor(ev[f"{name}_x"], dtype=torch.float32), names)
+        ptr = torch.from_numpy(ev[f"{name}_ptr"])
+        for mode in ("compat", "strict"):
+            nbr, deg = orc.knn_table(x, 8, ptr, [0, 1, 2], mode)
+            out[f"{name}_nbr_{mode}"] = nbr.numpy()
+        out[f"{name}_xstd"] = x.numpy()
+    # seeded DynEdge forward/backward on the DeepCore events (batch = 5) and synthetic (batch = 6)
+    torch.manual_seed(1234)
+    for name, F in (("deepcore", 7), ("prometheus", 4)):
+        x = torch.from_numpy(out[f"{name}_xstd"])
+        ptr = torch.from_numpy(ev[f"{name}_ptr"])
+        if name == "prometheus":   # config 1 = batch of 2: first two events with > 1 pulse
+            keep = [i for i in range(len(ptr) - 1) if ptr[i + 1] - ptr[i] > 1][:2]
+            x = torch.cat([x[ptr[i]:ptr[i + 1]] for i in keep])
+            n = torch.tensor([int(ptr[i + 1] - ptr[i]) for i in keep])
+            ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(n, 0)])
+            energy = torch.from_numpy(ev["prometheus_energy"][keep]).float()
+        else:
+            energy = torch.from_numpy(ev["deepcore_energy"]).float()
+        n_pulses = (ptr[1:] - ptr[:-1]).to(torch.int32)
+        batch = torch.repeat_interleave(torch.arange(len(n_pulses)), n_pulses.long())
+        ei = orc.knn_graph(x, 8, batch, [0, 1, 2])
+        torch.manual_seed(20241016)
+        model = orc.StandardModelOracle(F, global_pooling_schemes=["min", "max", "mean", "sum"])
+        pred = model(x, ei, batch, n_pulses)
+        loss = orc.log_cosh_loss(pred, torch.log10(energy).unsqueeze(1))
+        loss.backward()
+        out[f"{name}_model_x"] = x.numpy()
+        out[f"{name}_model_ptr"] = ptr.numpy()
+        out[f"{name}_model_energy"] = energy.numpy()
+        out[f"{name}_model_pred"] = pred.detach().numpy()
+        out[f"{name}_model_loss"] = loss.detach().numpy()
+        for k, p in model.named_parameters():
+            out[f"{name}_grad::{k}"] = p.grad.numpy()
+    b = synthetic_icecube86_batch(6, seed=20241016)
+    nbr, _ = orc.knn_table(b.x, 8, b.ptr.long(), [0, 1, 2], "compat")
+    out["synthetic6_x"] = b.x.numpy()
+    out["synthetic6_ptr"] = b.ptr.numpy()
+    out["synthetic6_nbr_compat"] = nbr.numpy()
+    np.savez_compressed(os.path.join(HERE, "oracle_expected.npz"), **out)
+    print("expected written")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("inputs", "all"):
+        make_inputs()
+    if what in ("expected", "all"):
+        make_expected()
