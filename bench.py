@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — events/s for DynEdge fwd+bwd(+Adam, +gradient all-reduce) on synthetic IceCube-86
+pulse graphs (BASELINE.json metric; workload = configs[1]), one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of B events already resident in HBM:
+layer-1 k-NN build, global variables, 4x(P|Q GEMM, fused EdgeConv, re-kNN), post MLP, pooling,
+readout, energy head, LogCosh, full backward, one flat RCCL all-reduce (N > 1), Adam step.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def build_model(dtype: str):
+    import graphnet_amd as g
+    torch.manual_seed(20241016)                       # identical initial weights on every rank
+    m = g.StandardModel(
+        graph_definition=g.KNNGraph(g.IceCube86()),
+        backbone=g.DynEdge(7, global_pooling_schemes=["min", "max", "mean", "sum"]),
+        tasks=[g.EnergyReconstruction(hidden_size=128, loss_function=g.LogCoshLoss(),
+                                      transform_prediction_and_target=torch.log10)],
+        optimizer_kwargs={"lr": 1e-3, "eps": 1e-3},
+    )
+    m.backbone.set_backend(dtype=dtype)
+    return m
+
+
+def algorithmic_flops(n_nodes: int, n_edges: int, n_events: int, F0: int = 19, n_pool: int = 4) -> float:
+    """Reference-formulation forward GEMM FLOPs, MAC = 2 FLOP."""
+    return 2.0 * (n_edges * (2 * F0 * 128 + 128 * 256) + 3 * n_edges * (512 * 336 + 336 * 256)
+                  + n_nodes * ((F0 + 1024) * 336 + 336 * 256) + n_events * (n_pool * 256 * 128 + 128))
+
+
+def cpu_baseline(events: int, steps: int):
+    """The oracle (plain-torch restatement of the PyG formulation) timed on the host cores."""
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    from oracle import dynedge_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(20241016)
+    m = orc.StandardModelOracle(7, global_pooling_schemes=["min", "max", "mean", "sum"], literal_distribute=True)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, eps=1e-3)
+    b = synthetic_icecube86_batch(events, seed=20241016)
+
+    def step():
+        ei = orc.knn_graph(b.x, 8, b.batch, [0, 1, 2])          # loader-side k-NN is part of the path
+        loss = m.loss(b.x, ei, b.batch, b.n_pulses, b.energy)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": events * steps / dt, "unit": "events/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} fwd+bwd+Adam steps of {events} synthetic IceCube-86 events (fp32, torch CPU, "
+                      f"{cores} threads; PyG not installed: in-repo restatement of the PyG formulation)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--events", type=int, default=1024, help="events per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-events", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from graphnet_amd import _lib, ops
+    from graphnet_amd.parallel import FlatGradAllReduce, broadcast_parameters
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    _lib.lib()                                           # fail loudly if the HIP library is missing
+
+    model = build_model(args.dtype).to(dev)
+    broadcast_parameters(model)
+    sync = FlatGradAllReduce(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-3)
+    batch = synthetic_icecube86_batch(args.events, seed=20241016 + rank).to(dev)   # disjoint shards (weak scaling)
+    n_nodes = int(batch.x.shape[0])
+
+    def step():
+        sync.zero_grad()
+        loss = model.shared_step(batch)
+        loss.backward()
+        sync()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.enable_timers(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timers = ops.timer_summary()
+    ops.enable_timers(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        total_events = args.events * world * args.steps
+        # edges of the layer-1 graph (degree k or k+1) ~ edges of every layer
+        with torch.no_grad():
+            from graphnet_amd import ops as _o
+            t = _o.knn_graph(batch.x, [0, 1, 2], batch.batch.to(torch.int32), batch.ptr.to(torch.int32), 8)
+            n_edges = int((t.nbr >= 0).sum().item()) + int(t.ovf_cnt.item())
+        flops_fwd = algorithmic_flops(n_nodes, n_edges, args.events)
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        # dominant kernel (by HIP-event time on the launch stream) and its own algorithmic FLOPs
+        dom = max(timers.items(), key=lambda kv: kv[1][1]) if timers else ("none", (1, 0.0))
+        name, (launches, ms) = dom
+        per_launch_ms = ms / max(launches, 1)
+        kernel_flops = {
+            # per launch, layers 2-4 shape (H1=336, H2=256); layer 1 (H1=128) is averaged in
+            "edgeconv_fwd": 2.0 * n_edges * 256 * (3 * 336 + 128) / 4,
+            "edgeconv_bwd": 2.0 * n_edges * 256 * (3 * 336 + 128) / 4,
+            "edgeconv_dw2": 2.0 * n_edges * 256 * (3 * 336 + 128) / 4,
+        }.get(name)
+        if kernel_flops is None:                       # a per-node GEMM dominates: price the whole path instead
+            kernel_flops = 3.0 * flops_fwd / max(launches / args.steps, 1)
+        achieved = kernel_flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
+        out = {
+            "metric": "events/sec DynEdge fwd+bwd, IceCube-86 k=8",
+            "value": total_events / dt, "unit": "events/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: DynEdge energy regression, synthetic IceCube-86 pulses "
+                                   "(~150/event, 7 features), k=8, fwd+bwd+Adam",
+                       "events_per_gpu": args.events, "pulses_per_gpu": n_nodes, "edges_per_layer": n_edges,
+                       "parallelism": f"dp{world} (event shards, one flat RCCL all-reduce)"},
+            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "launch_ms": per_launch_ms, "launches_per_step": launches / args.steps},
+            "path_roofline": {"algorithmic_tflop_per_step": 3.0 * flops_fwd * world / 1e12,
+                              "achieved_tflops": 3.0 * flops_fwd * world * args.steps / dt / 1e12,
+                              "frac_of_peak": 3.0 * flops_fwd * args.steps / dt / 1e12 / peak},
+            "phase_ms_per_step": {k: v[1] / args.steps for k, v in sorted(timers.items(), key=lambda kv: -kv[1][1])},
+            "final_loss": float(loss),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_events, args.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

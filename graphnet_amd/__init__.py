@@ -6,5 +6,13 @@ hand-written gfx950 HIP kernels (``include/graphnet_amd.h``).  Importing the pac
 needs a GPU; calling a device op without the built library raises ``RuntimeError``.
 """
 from .data import Batch, Data, collate_fn  # noqa: F401
+from .detector import Detector, IceCube86, IceCubeDeepCore, IceCubeUpgrade, ORCA150SuperDense, Prometheus  # noqa: F401
+from .model import Model, ModelConfig  # noqa: F401
+from .graphs import GraphDefinition, KNNEdges, KNNGraph, NodesAsPulses  # noqa: F401
+from .gnn import GNN, DynEdge  # noqa: F401
+from .standard_model import (  # noqa: F401
+    EnergyReconstruction, IdentityTask, LogCoshLoss, LossFunction, MSELoss, PiecewiseLinearLR,
+    StandardLearnedTask, StandardModel, Task,
+)
 
 __version__ = "0.1.0"

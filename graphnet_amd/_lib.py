@@ -1,0 +1,85 @@
+"""ctypes binding of ``libgraphnet_amd.so`` (C ABI: ``include/graphnet_amd.h``).
+
+The library is built in-tree by ``graphnet_amd/csrc/Makefile`` (``__graft_entry__.build()``).
+There is no fallback: if the shared object is missing every device op raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgraphnet_amd.so")
+_lib = None
+
+P = c_void_p
+I32 = c_int32
+I64 = c_int64
+
+# name -> (restype, argtypes); mirrors include/graphnet_amd.h one to one
+SIGNATURES = {
+    "gn_last_error": (c_char_p, []),
+    "gn_abi_version": (I32, []),
+    "gn_knn_graph": (I32, [P, I64, P, I32, P, P, I32, I32, I32, P, P, P]),
+    "gn_scan_tmp_ints": (I64, [I64]),
+    "gn_scan_i32": (I32, [P, P, I32, P, P, P]),
+    "gn_ovf_compact": (I32, [P, I32, P, P, P, P, P, P]),
+    "gn_edge_slots": (I32, [I32]),
+    "gn_rev_build": (I32, [P, I32, I32, P, P, P, P, P, P, P]),
+    "gn_table_degree": (I32, [P, P, I32, I32, P, P]),
+    "gn_table_to_edge_index": (I32, [P, P, I32, I32, P, I64, P, P]),
+    "gn_edge_index_to_table": (I32, [P, I64, I32, I32, P, P, P, P, P]),
+    "gn_ptr_to_batch": (I32, [P, I32, P, P]),
+    "gn_graph_globals": (I32, [P, I64, I32, P, I32, P, P, I32, P, P, P]),
+    "gn_concat_globals": (I32, [P, I64, I32, P, I32, P, I32, P, I32, P]),
+    "gn_linear_fwd": (I32, [I32, I32, P, P, P, P, I32, P, I32, I32, I32, P, P, I64, I32, I32, P, I64, I32, P]),
+    "gn_linear_wgrad_splits": (I32, [I32]),
+    "gn_linear_wgrad": (I32, [I32, P, I64, I32, I32, P, P, P, I32, P, P, I32, P]),
+    "gn_colsum_blocks": (I32, [I32]),
+    "gn_colsum": (I32, [P, I64, I32, I32, P, P, I32, P]),
+    "gn_reduce_slabs": (I32, [P, I32, I64, P, I32, P]),
+    "gn_edgeconv_fwd": (I32, [I32, P, P, P, P, I32, I32, P, I32, P, P, I32, P, I64, P, P]),
+    "gn_edgeconv_bwd": (I32, [I32, P, P, P, P, I32, I32, P, I32, I32, P, I64, P, P, I32, P, P, I64, P]),
+    "gn_edgeconv_dw2_splits": (I32, [I64]),
+    "gn_edgeconv_dw2": (I32, [I32, P, P, P, P, I32, I32, P, I32, I32, I32, P, I64, P, P, P, I32, P]),
+    "gn_edgeconv_dq_gather": (I32, [I32, P, I32, P, P, I32, P, I64, P]),
+    "gn_segment_pool_fwd": (I32, [P, I64, I32, P, I32, P, I32, P, P, P, P]),
+    "gn_segment_pool_bwd": (I32, [P, I32, P, P, I32, P, I32, P, P, P, I64, P, I64, P]),
+}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``libgraphnet_amd.so`` (in-tree)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j", "6"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building libgraphnet_amd.so failed")
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load the C-ABI library (never falls back to anything else)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "graphnet_amd has no CPU fallback for device ops."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(lib().gn_last_error().decode())

@@ -1,0 +1,433 @@
+"""``GNN`` plugin base class and the MI355X-native ``DynEdge`` backbone.
+
+Drop-in for ``graphnet.models.gnn.DynEdge`` (reference ``models/gnn/dynedge.py:21-349``,
+plugin ABC ``models/gnn/gnn.py:11-35``): identical keyword signature, identical sub-module
+names (``_conv_layers.{l}.nn.{0,2}``, ``_post_processing.{0,2}``, ``_readout.{0}``) so that
+reference state-dicts load unchanged, identical output.  Everything between ``data.x`` and the
+pooled features runs in ``libgraphnet_amd.so`` (one ``torch.autograd.Function`` orchestrating
+the kernels); the tiny read-out MLP on ``[B, 1024]`` stays in torch.
+"""
+from __future__ import annotations
+
+from typing import Any, List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import Tensor
+
+from . import ops
+from .model import Model
+
+GLOBAL_POOLINGS = ("min", "max", "sum", "mean")
+
+
+class GNN(Model):
+    """Base class for all core GNN models (``models/gnn/gnn.py:11-35``)."""
+
+    def __init__(self, nb_inputs: int, nb_outputs: int) -> None:
+        super().__init__()
+        self._nb_inputs = nb_inputs
+        self._nb_outputs = nb_outputs
+
+    @property
+    def nb_inputs(self) -> int:
+        return self._nb_inputs
+
+    @property
+    def nb_outputs(self) -> int:
+        return self._nb_outputs
+
+    def forward(self, data: Any) -> Tensor:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+
+class _ConvParams(torch.nn.Module):
+    """Holds the edge MLP under the attribute name ``nn`` (PyG ``EdgeConv.nn``) so the
+    state-dict keys equal the reference's ``_conv_layers.{l}.nn.{idx}.{weight,bias}``."""
+
+    def __init__(self, mlp: torch.nn.Sequential, nb_neighbors: int, features_subset: Any):
+        super().__init__()
+        self.nn = mlp
+        self.nb_neighbors = nb_neighbors
+        self.features_subset = features_subset
+
+
+def _maybe(data: Any, key: str) -> Any:
+    try:
+        return data[key] if key in data else None
+    except TypeError:
+        return getattr(data, key, None)
+
+
+def _subset_cols(subset: Union[slice, Sequence[int]], width: int) -> List[int]:
+    if isinstance(subset, slice):
+        return list(range(width))[subset]
+    return [int(c) for c in subset]
+
+
+def _kw(w: int) -> int:
+    """Kernel-side width of a segment: float4 granularity (the pad columns hold zeros)."""
+    return ops.round_up(w, 4)
+
+
+def _ksegs(segs: Sequence[Tuple[Tensor, int]]) -> List[Tuple[Tensor, int]]:
+    return [(t, _kw(w)) for t, w in segs]
+
+
+def _unpad_cols(dW: Tensor, widths: Sequence[int]) -> Tensor:
+    """Drop the float4 pad columns of each segment from a weight gradient."""
+    if all(w == _kw(w) for w in widths):
+        return dW
+    parts, off = [], 0
+    for w in widths:
+        parts.append(dW[:, off: off + w])
+        off += _kw(w)
+    return torch.cat(parts, dim=1)
+
+
+class _DynEdgeFunction(torch.autograd.Function):
+    """x, graph -> node features after the post-processing MLP (optionally pooled).
+
+    forward/backward only enqueue kernels of the C ABI on the current stream.
+    """
+
+    @staticmethod
+    def forward(ctx, cfg: dict, x: Tensor, *params: Tensor) -> Tensor:  # type: ignore[override]
+        mode = cfg["mode"]
+        dt = ops.mode_dtype(mode)
+        lowp = mode == ops.MODE_BF16
+        batch, ptr, g = cfg["batch"], cfg["ptr"], cfg["graph"]
+        nconv, npost = cfg["nconv"], cfg["npost"]
+        conv_p = [params[4 * l: 4 * l + 4] for l in range(nconv)]
+        post_p = [params[4 * nconv + 2 * t: 4 * nconv + 2 * t + 2] for t in range(npost)]
+        N, F = int(x.shape[0]), int(x.shape[1])
+
+        gv = cfg["globals"]
+        G = 0 if (gv is None or cfg["globals_after"]) else int(gv.shape[1])
+        F0 = F + G
+        x0 = ops.concat_globals(x, gv if G else None, batch, ops.round_up(F0, 32))
+        xs: List[Tuple[Tensor, int]] = [(x0, F0)]
+        graphs, PQs, masks = [], [], []
+        for l, (W1, b1, W2, b2) in enumerate(conv_p):
+            xin, Fin = xs[-1]
+            H1, H2 = int(W1.shape[0]), int(W2.shape[0])
+            H1p = ops.round_up(H1, 32)
+            Wa, Wb = W1[:, :Fin], W1[:, Fin:]
+            Wpq = torch.zeros((2 * H1p, Fin), dtype=torch.float32, device=x.device)
+            Wpq[:H1] = Wa - Wb
+            Wpq[H1p:H1p + H1] = Wb
+            bpq = torch.zeros(2 * H1p, dtype=torch.float32, device=x.device)
+            bpq[:H1] = b1
+            PQ = ops.linear_fwd(mode, [(xin, _kw(Fin))], ops.pack_weight(Wpq, [Fin], dt), 2 * H1p, bias=bpq,
+                                out_lowp=lowp)
+            out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, ops.pack_weight(W2, [H1], dt), b2.contiguous(), H2)
+            graphs.append(g); PQs.append(PQ); masks.append(mask)
+            xs.append((out, H2))
+            if l + 1 < nconv:
+                g = ops.knn_graph(out, _subset_cols(cfg["features_subset"], H2), batch, ptr, cfg["k"],
+                                  strict=cfg["strict"])
+        ys: List[Tuple[Tensor, int]] = []
+        segs = xs
+        for (W, b) in post_p:
+            y = ops.linear_fwd(mode, _ksegs(segs), ops.pack_weight(W, [w for _, w in segs], dt), int(W.shape[0]),
+                               bias=b.contiguous(), relu=True)
+            ys.append((y, int(W.shape[0])))
+            segs = [ys[-1]]
+        y_last, P = ys[-1]
+        ctx.cfg, ctx.xs, ctx.graphs, ctx.PQs, ctx.masks, ctx.ys = cfg, xs, graphs, PQs, masks, ys
+        ctx.params = params
+        ctx.amin = ctx.amax = None
+        cfg["trace"] = {"conv_out": [t for t, _ in xs], "graphs": graphs, "post": y_last} if cfg.get("want_trace") else None
+        if cfg["pools"]:
+            pooled, ctx.amin, ctx.amax = ops.segment_pool_fwd(y_last, P, ptr, cfg["pools"])
+            return pooled
+        return y_last
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):  # type: ignore[override]
+        cfg = ctx.cfg
+        mode = cfg["mode"]
+        dt = ops.mode_dtype(mode)
+        batch, ptr = cfg["batch"], cfg["ptr"]
+        nconv, npost = cfg["nconv"], cfg["npost"]
+        params = ctx.params
+        conv_p = [params[4 * l: 4 * l + 4] for l in range(nconv)]
+        post_p = [params[4 * nconv + 2 * t: 4 * nconv + 2 * t + 2] for t in range(npost)]
+        xs, ys = ctx.xs, ctx.ys
+        N = int(xs[0][0].shape[0])
+        dev = xs[0][0].device
+        grads: List[Optional[Tensor]] = [None] * len(params)
+
+        y_last, P = ys[-1]
+        gout = gout.contiguous().to(torch.float32)
+        if cfg["pools"]:
+            dZ = ops.segment_pool_bwd(gout, P, ptr, batch, N, cfg["pools"], ctx.amin, ctx.amax, y_last)
+        else:
+            dZ = gout * (y_last > 0)
+
+        # ---- post-processing MLP, last layer first
+        seg_pad = [ops.round_up(w, 32) for _, w in xs]
+        seg_off = [sum(seg_pad[:i]) for i in range(len(xs))]
+        dXcat = None
+        for t in reversed(range(npost)):
+            W, b = post_p[t]
+            Pt = int(W.shape[0])
+            in_segs = xs if t == 0 else [ys[t - 1]]
+            grads[4 * nconv + 2 * t] = _unpad_cols(ops.linear_wgrad(mode, dZ, Pt, _ksegs(in_segs)),
+                                                   [w for _, w in in_segs])
+            grads[4 * nconv + 2 * t + 1] = ops.colsum(dZ, Pt)
+            if t > 0:
+                yprev, Pprev = ys[t - 1]
+                dZ = ops.linear_fwd(mode, [(dZ, Pt)], ops.pack_weight(W.t(), [Pt], dt), Pprev, gate=yprev)
+            else:
+                WT = torch.zeros((sum(seg_pad), Pt), dtype=torch.float32, device=dev)
+                off = 0
+                for s, (_, w) in enumerate(xs):
+                    WT[seg_off[s]: seg_off[s] + w] = W[:, off: off + w].t()
+                    off += w
+                dXcat = ops.linear_fwd(mode, [(dZ, Pt)], ops.pack_weight(WT, [Pt], dt), sum(seg_pad))
+
+        # ---- DynEdgeConv layers, last first
+        for l in reversed(range(nconv)):
+            W1, b1, W2, b2 = conv_p[l]
+            xin, Fin = xs[l]
+            H1, H2 = int(W1.shape[0]), int(W2.shape[0])
+            H1p = ops.round_up(H1, 32)
+            g, PQ, mask = ctx.graphs[l], ctx.PQs[l], ctx.masks[l]
+            g_out = dXcat[:, seg_off[l + 1]: seg_off[l + 1] + H2]
+            dPQ = torch.empty((N, 2 * H1p), dtype=torch.float32, device=dev)
+            dpre = torch.empty((max(g.rows, 1), H1p), dtype=dt, device=dev)
+            ops.edgeconv_bwd(mode, g, PQ, H1p, H2, g_out, mask, ops.pack_weight(W2.t(), [H2], dt), dpre,
+                             dPQ[:, :H1p])
+            dW2, db2 = ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, g_out, mask)
+            ops.edgeconv_dq_gather(mode, g, dpre, H1p, dPQ[:, H1p:])
+            dWpq = ops.linear_wgrad(mode, dPQ, 2 * H1p, [(xin, _kw(Fin))])[:, :Fin]
+            dWp, dWq = dWpq[:H1], dWpq[H1p:H1p + H1]
+            grads[4 * l] = torch.cat([dWp, dWq - dWp], dim=1)
+            grads[4 * l + 1] = ops.colsum(dPQ, H1)
+            grads[4 * l + 2] = dW2
+            grads[4 * l + 3] = db2
+            if l > 0:
+                Wa, Wb = W1[:, :Fin], W1[:, Fin:]
+                WpqT = torch.zeros((Fin, 2 * H1p), dtype=torch.float32, device=dev)
+                WpqT[:, :H1] = (Wa - Wb).t()
+                WpqT[:, H1p:H1p + H1] = Wb.t()
+                ops.linear_fwd(mode, [(dPQ, 2 * H1p)], ops.pack_weight(WpqT, [2 * H1p], dt), Fin,
+                               out=dXcat[:, seg_off[l]: seg_off[l] + Fin], accum=True)
+        return (None, None) + tuple(grads)
+
+
+class DynEdge(GNN):
+    """DynEdge (dynamical edge convolutional) model on hand-written gfx950 kernels.
+
+    Constructor arguments are those of the reference (``dynedge.py:24-38``).  Extra,
+    keyword-only backend switches (not part of the reference config) are set afterwards with
+    :meth:`set_backend`.
+    """
+
+    def __init__(
+        self,
+        nb_inputs: int,
+        *,
+        nb_neighbours: int = 8,
+        features_subset: Optional[Union[List[int], slice]] = None,
+        dynedge_layer_sizes: Optional[List[Tuple[int, ...]]] = None,
+        post_processing_layer_sizes: Optional[List[int]] = None,
+        readout_layer_sizes: Optional[List[int]] = None,
+        global_pooling_schemes: Optional[Union[str, List[str]]] = None,
+        add_global_variables_after_pooling: bool = False,
+        activation_layer: Optional[str] = None,
+        add_norm_layer: bool = False,
+        skip_readout: bool = False,
+    ):
+        if features_subset is None:
+            features_subset = slice(0, 3)
+        if dynedge_layer_sizes is None:
+            dynedge_layer_sizes = [(128, 256), (336, 256), (336, 256), (336, 256)]
+        assert isinstance(dynedge_layer_sizes, list)
+        assert len(dynedge_layer_sizes)
+        assert all(isinstance(sizes, tuple) for sizes in dynedge_layer_sizes)
+        assert all(len(sizes) > 0 for sizes in dynedge_layer_sizes)
+        assert all(all(size > 0 for size in sizes) for sizes in dynedge_layer_sizes)
+        self._dynedge_layer_sizes = dynedge_layer_sizes
+
+        if post_processing_layer_sizes is None:
+            post_processing_layer_sizes = [336, 256]
+        assert isinstance(post_processing_layer_sizes, list)
+        assert len(post_processing_layer_sizes)
+        assert all(size > 0 for size in post_processing_layer_sizes)
+        self._post_processing_layer_sizes = post_processing_layer_sizes
+
+        if readout_layer_sizes is None:
+            readout_layer_sizes = [128]
+        assert isinstance(readout_layer_sizes, list)
+        assert len(readout_layer_sizes)
+        assert all(size > 0 for size in readout_layer_sizes)
+        self._readout_layer_sizes = readout_layer_sizes
+
+        if isinstance(global_pooling_schemes, str):
+            global_pooling_schemes = [global_pooling_schemes]
+        if isinstance(global_pooling_schemes, list):
+            for pooling_scheme in global_pooling_schemes:
+                assert pooling_scheme in GLOBAL_POOLINGS, f"Global pooling scheme {pooling_scheme} not supported."
+        else:
+            assert global_pooling_schemes is None
+        self._global_pooling_schemes = global_pooling_schemes
+
+        if add_global_variables_after_pooling:
+            assert self._global_pooling_schemes, (
+                "No global pooling schemes were request, so cannot add global variables after pooling."
+            )
+        self._add_global_variables_after_pooling = add_global_variables_after_pooling
+
+        if activation_layer is None or activation_layer.lower() == "relu":
+            activation: torch.nn.Module = torch.nn.ReLU()
+        elif activation_layer.lower() == "gelu":
+            activation = torch.nn.GELU()
+        else:
+            raise ValueError(f"Activation layer {activation_layer} not supported.")
+
+        super().__init__(nb_inputs, self._readout_layer_sizes[-1])
+
+        self._activation = activation
+        self._nb_inputs = nb_inputs
+        self._nb_global_variables = 5 + nb_inputs
+        self._nb_neighbours = nb_neighbours
+        self._features_subset = features_subset
+        self._add_norm_layer = add_norm_layer
+        self._skip_readout = skip_readout
+        # backend switches (see set_backend)
+        self._compute_mode = ops.MODE_BF16
+        self._knn_strict = False
+        self._graph_columns = [0, 1, 2]
+        self._construct_layers()
+
+    # reference: dynedge.py:183-249 (same module tree, same parameter names)
+    def _construct_layers(self) -> None:
+        nb_input_features = self._nb_inputs
+        if not self._add_global_variables_after_pooling:
+            nb_input_features += self._nb_global_variables
+        self._conv_layers = torch.nn.ModuleList()
+        nb_latent_features = nb_input_features
+        nb_out = nb_latent_features
+        for sizes in self._dynedge_layer_sizes:
+            layers: List[torch.nn.Module] = []
+            layer_sizes = [nb_latent_features] + list(sizes)
+            for ix, (nb_in, nb_out) in enumerate(zip(layer_sizes[:-1], layer_sizes[1:])):
+                if ix == 0:
+                    nb_in *= 2
+                layers.append(torch.nn.Linear(nb_in, nb_out))
+                if self._add_norm_layer:
+                    layers.append(torch.nn.LayerNorm(nb_out))
+                layers.append(self._activation)
+            self._conv_layers.append(
+                _ConvParams(torch.nn.Sequential(*layers), self._nb_neighbours, self._features_subset))
+            nb_latent_features = nb_out
+
+        nb_latent_features = sum(sizes[-1] for sizes in self._dynedge_layer_sizes) + nb_input_features
+        post_processing_layers: List[torch.nn.Module] = []
+        layer_sizes = [nb_latent_features] + list(self._post_processing_layer_sizes)
+        for nb_in, nb_out in zip(layer_sizes[:-1], layer_sizes[1:]):
+            post_processing_layers.append(torch.nn.Linear(nb_in, nb_out))
+            if self._add_norm_layer:
+                post_processing_layers.append(torch.nn.LayerNorm(nb_out))
+            post_processing_layers.append(self._activation)
+        self._post_processing = torch.nn.Sequential(*post_processing_layers)
+
+        nb_poolings = len(self._global_pooling_schemes) if self._global_pooling_schemes else 1
+        nb_latent_features = nb_out * nb_poolings
+        if self._add_global_variables_after_pooling:
+            nb_latent_features += self._nb_global_variables
+        readout_layers: List[torch.nn.Module] = []
+        layer_sizes = [nb_latent_features] + list(self._readout_layer_sizes)
+        for nb_in, nb_out in zip(layer_sizes[:-1], layer_sizes[1:]):
+            readout_layers.append(torch.nn.Linear(nb_in, nb_out))
+            readout_layers.append(self._activation)
+        self._readout = torch.nn.Sequential(*readout_layers)
+
+    # ------------------------------------------------------------------ backend control
+    def set_backend(self, *, dtype: str = "bf16", knn_mode: str = "compat",
+                    graph_columns: Optional[List[int]] = None) -> "DynEdge":
+        """``dtype``: "bf16" (MFMA bf16 operands, fp32 accumulate) or "fp32" (exact-f32 MFMA,
+        parity mode).  ``knn_mode``: "compat" (k+1-with-self then mask, as knn_graph) or
+        "strict".  ``graph_columns``: columns for the layer-1 k-NN when the batch carries no
+        ``edge_index`` (KNNGraph default ``[0, 1, 2]``, ``graphs/graphs.py:25``)."""
+        self._compute_mode = {"bf16": ops.MODE_BF16, "fp32": ops.MODE_F32, "f32": ops.MODE_F32}[dtype]
+        self._knn_strict = {"compat": False, "strict": True}[knn_mode]
+        if graph_columns is not None:
+            self._graph_columns = list(graph_columns)
+        return self
+
+    def _check_supported(self) -> None:
+        if not isinstance(self._activation, torch.nn.ReLU) or self._add_norm_layer:
+            raise NotImplementedError(
+                "graphnet_amd.DynEdge: the HIP path implements activation_layer='relu' without norm layers "
+                "(the reference default); GELU / LayerNorm epilogues are not built yet and there is no fallback.")
+        if any(len(s) != 2 for s in self._dynedge_layer_sizes):
+            raise NotImplementedError("graphnet_amd.DynEdge: each DynEdgeConv MLP must have exactly two layers.")
+
+    def _csr(self, data: Any, x: Tensor):
+        N = int(x.shape[0])
+        n_pulses = data.n_pulses.to(torch.int32)
+        ptr = _maybe(data, "ptr")
+        if ptr is None:
+            ptr = torch.zeros(n_pulses.shape[0] + 1, dtype=torch.int64, device=x.device)
+            ptr[1:] = torch.cumsum(torch.bincount(data.batch, minlength=n_pulses.shape[0]), 0)
+        ptr32 = ptr.to(torch.int32)
+        batch = _maybe(data, "batch")
+        batch32 = batch.to(torch.int32) if batch is not None else ops.ptr_to_batch(ptr32, N)
+        return ptr32, batch32, n_pulses
+
+    def _layer0_graph(self, data: Any, x: Tensor, batch32: Tensor, ptr32: Tensor) -> ops.NeighbourTable:
+        table = _maybe(data, "nbr_table")
+        if isinstance(table, ops.NeighbourTable):
+            return table
+        ei = _maybe(data, "edge_index")
+        if ei is not None:
+            return ops.table_from_edge_index(ei, int(x.shape[0]), self._nb_neighbours)
+        k, cols = self._nb_neighbours, self._graph_columns
+        knn_k = _maybe(data, "knn_k")
+        if knn_k is not None:       # recorded by KNNEdges on a CPU Data: same k / columns, built here
+            k = int(knn_k.reshape(-1)[0]) if isinstance(knn_k, Tensor) else int(knn_k)
+            kc = _maybe(data, "knn_columns")
+            cols = list(kc[0]) if isinstance(kc, list) and kc and isinstance(kc[0], (list, tuple)) else list(kc)
+        return ops.knn_graph(x, cols, batch32, ptr32, k, strict=self._knn_strict)
+
+    def _kernel_params(self) -> List[Tensor]:
+        ps: List[Tensor] = []
+        for conv in self._conv_layers:
+            lin = [m for m in conv.nn if isinstance(m, torch.nn.Linear)]
+            ps += [lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias]
+        for m in self._post_processing:
+            if isinstance(m, torch.nn.Linear):
+                ps += [m.weight, m.bias]
+        return ps
+
+    def forward(self, data: Any, return_trace: bool = False) -> Tensor:
+        """Apply learnable forward pass (``dynedge.py:295-349``)."""
+        self._check_supported()
+        x = data.x
+        if not x.is_cuda:
+            raise RuntimeError("graphnet_amd.DynEdge runs on an MI355X (HIP) device only; move the batch to 'cuda'.")
+        x = x.to(torch.float32)
+        ptr32, batch32, n_pulses = self._csr(data, x)
+        g0 = self._layer0_graph(data, x, batch32, ptr32)
+        gv = ops.graph_globals(x, ptr32, g0, n_pulses)
+        cfg = {
+            "mode": self._compute_mode, "batch": batch32, "ptr": ptr32, "graph": g0,
+            "nconv": len(self._conv_layers),
+            "npost": sum(isinstance(m, torch.nn.Linear) for m in self._post_processing),
+            "globals": gv, "globals_after": self._add_global_variables_after_pooling,
+            "features_subset": self._features_subset, "k": self._nb_neighbours, "strict": self._knn_strict,
+            "pools": None if self._skip_readout else self._global_pooling_schemes,
+            "want_trace": return_trace,
+        }
+        out = _DynEdgeFunction.apply(cfg, x, *self._kernel_params())
+        if not self._skip_readout:
+            if self._global_pooling_schemes and self._add_global_variables_after_pooling:
+                out = torch.cat([out, gv], dim=1)
+            out = self._readout(out)
+        if return_trace:
+            trace = cfg["trace"] or {}
+            trace["global_variables"] = gv
+            return out, trace
+        return out

@@ -1,0 +1,183 @@
+"""Graph definitions: ``GraphDefinition`` / ``KNNGraph`` / ``KNNEdges`` / ``NodesAsPulses``.
+
+Host-side mirror of ``models/graphs/graph_definition.py:148-248``, ``graphs/graphs.py:13-58``,
+``graphs/edges/edges.py:47-80`` and ``graphs/nodes/nodes.py:123-132``.
+
+Difference by design: the reference builds k-NN edges on the CPU, one event
+at a time, inside DataLoader workers.  Here a CPU ``Data`` leaves ``edge_index`` unset and the
+backbone builds the whole batch's layer-1 graph with one ``gn_knn_graph`` launch on the GPU
+(same columns, same k, same result).  On a GPU tensor ``KNNEdges`` runs the HIP kernel at once.
+There is no CPU k-NN in this package.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+from numpy.random import Generator, default_rng
+
+from .data import Data
+from .detector import Detector
+from .model import Model
+
+
+class NodeDefinition(Model):
+    def forward(self, x: torch.Tensor):
+        graph = self._construct_nodes(x)
+        return graph, self._output_feature_names
+
+    def set_output_feature_names(self, input_feature_names: List[str]) -> None:
+        self._output_feature_names = list(input_feature_names)
+
+    @property
+    def nb_outputs(self) -> int:
+        return len(self._output_feature_names)
+
+
+class NodesAsPulses(NodeDefinition):
+    """Each pulse is a node (``nodes/nodes.py:123-132``)."""
+
+    def _construct_nodes(self, x: torch.Tensor) -> Data:
+        return Data(x=x)
+
+
+class EdgeDefinition(Model):
+    def forward(self, graph: Data) -> Data:
+        return self._construct_edges(graph)
+
+
+class KNNEdges(EdgeDefinition):
+    """k-nearest-neighbour edges in the space of ``columns`` (``edges.py:47-80``)."""
+
+    def __init__(self, nb_nearest_neighbours: int, columns: List[int] = [0, 1, 2]):
+        super().__init__()
+        self._nb_nearest_neighbours = nb_nearest_neighbours
+        self._columns = list(columns)
+
+    def _construct_edges(self, graph: Data) -> Data:
+        x = graph.x
+        if x.is_cuda:
+            from . import ops
+            n = int(x.shape[0])
+            batch = getattr(graph, "batch", None) if "batch" in graph else None
+            if batch is None:
+                ptr = torch.tensor([0, n], dtype=torch.int32, device=x.device)
+                batch32 = torch.zeros(n, dtype=torch.int32, device=x.device)
+            else:
+                batch32 = batch.to(torch.int32)
+                counts = torch.bincount(batch)
+                ptr = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=x.device)
+                ptr[1:] = torch.cumsum(counts, 0)
+            table = ops.knn_graph(x.to(torch.float32), self._columns, batch32, ptr, self._nb_nearest_neighbours)
+            graph.edge_index = table.edge_index()
+        else:
+            graph.edge_index = None            # built on device for the whole batch by the backbone
+        graph.knn_k = self._nb_nearest_neighbours
+        graph.knn_columns = list(self._columns)
+        return graph
+
+
+class GraphDefinition(Model):
+    """numpy pulses -> ``Data`` (``graph_definition.py:27-248``; mask / inactive-sensor options
+    of the reference are data-side conveniences outside the hot path and not mirrored)."""
+
+    def __init__(
+        self,
+        detector: Detector,
+        node_definition: Optional[NodeDefinition] = None,
+        edge_definition: Optional[EdgeDefinition] = None,
+        input_feature_names: Optional[List[str]] = None,
+        dtype: Optional[torch.dtype] = torch.float,
+        perturbation_dict: Optional[Dict[str, float]] = None,
+        seed: Optional[Union[int, Generator]] = None,
+        sort_by: Optional[str] = None,
+    ):
+        super().__init__()
+        self._detector = detector
+        self._node_definition = node_definition or NodesAsPulses()
+        self._edge_definition = edge_definition
+        self._perturbation_dict = perturbation_dict
+        self._sort_by = None
+        if input_feature_names is None:
+            input_feature_names = list(detector.feature_map().keys())
+        self._input_feature_names = list(input_feature_names)
+        if sort_by is not None:
+            self._sort_by = self._input_feature_names.index(sort_by)
+        self._node_definition.set_output_feature_names(self._input_feature_names)
+        self.nb_inputs = len(self._input_feature_names)
+        self.nb_outputs = self._node_definition.nb_outputs
+        self.dtype = dtype
+        if isinstance(seed, Generator):
+            self.rng = seed
+        elif seed is None:
+            self.rng = default_rng()
+        elif isinstance(seed, int):
+            self.rng = default_rng(seed)
+        else:
+            raise ValueError("Invalid seed. Must be an int or a numpy Generator.")
+
+    def _validate_input(self, input_features: np.ndarray, input_feature_names: List[str]) -> None:
+        assert input_features.shape[1] == len(input_feature_names)
+        assert list(input_feature_names) == self._input_feature_names, (
+            f"Input features ({input_feature_names}) is not what {self.__class__.__name__} was "
+            f"instantiated with ({self._input_feature_names})")
+
+    def _perturb_input(self, input_features: np.ndarray) -> np.ndarray:
+        if isinstance(self._perturbation_dict, dict):
+            cols = [self._input_feature_names.index(k) for k in self._perturbation_dict]
+            sig = np.array(list(self._perturbation_dict.values()))
+            input_features[:, cols] = self.rng.normal(loc=input_features[:, cols], scale=sig)
+        return input_features
+
+    def forward(self, input_features: np.ndarray, input_feature_names: List[str],
+                truth_dicts: Optional[List[Dict[str, Any]]] = None,
+                custom_label_functions: Optional[Dict[str, Callable[..., Any]]] = None,
+                **_unused: Any) -> Data:
+        self._validate_input(input_features, input_feature_names)
+        input_features = self._perturb_input(input_features)
+        x = torch.tensor(input_features, dtype=self.dtype)
+        x = self._detector(x, input_feature_names)
+        graph, _names = self._node_definition(x)
+        if self._sort_by is not None:
+            graph.x = graph.x[graph.x[:, self._sort_by].sort()[1]]
+        graph.x = graph.x.type(self.dtype)
+        graph.n_pulses = torch.tensor(len(input_features), dtype=torch.int32)
+        if self._edge_definition is not None:
+            graph = self._edge_definition(graph)
+        if truth_dicts is not None:
+            for td in truth_dicts:
+                for k, v in td.items():
+                    graph[k] = torch.tensor(v)
+        if custom_label_functions is not None:
+            for k, fn in custom_label_functions.items():
+                graph[k] = fn(graph)
+        graph["graph_definition"] = self.__class__.__name__
+        return graph
+
+
+class KNNGraph(GraphDefinition):
+    """Edges drawn to the k nearest neighbours (``graphs/graphs.py:13-58``)."""
+
+    def __init__(
+        self,
+        detector: Detector,
+        node_definition: NodeDefinition = None,
+        input_feature_names: Optional[List[str]] = None,
+        dtype: Optional[torch.dtype] = torch.float,
+        perturbation_dict: Optional[Dict[str, float]] = None,
+        seed: Optional[Union[int, Generator]] = None,
+        nb_nearest_neighbours: int = 8,
+        columns: List[int] = [0, 1, 2],
+        **kwargs: Any,
+    ) -> None:
+        super().__init__(
+            detector=detector,
+            node_definition=node_definition or NodesAsPulses(),
+            edge_definition=KNNEdges(nb_nearest_neighbours=nb_nearest_neighbours, columns=columns),
+            dtype=dtype,
+            input_feature_names=input_feature_names,
+            perturbation_dict=perturbation_dict,
+            seed=seed,
+            **kwargs,
+        )

@@ -1,0 +1,130 @@
+"""``Model`` base class: config capture + state-dict helpers of the reference's ``Model``.
+
+Mirrors the parts of ``models/model.py:20-108`` and
+``utilities/config/model_config.py:317-346`` that the DynEdge path relies on, without
+Lightning / ruamel: constructor arguments (with defaults) are captured at construction so a
+model can be rebuilt by class name (``ModelConfig``), ``save_state_dict`` / ``load_state_dict``
+accept paths or dicts and rename legacy ``_gnn.`` keys to ``backbone.`` (``model.py:72-74``).
+"""
+from __future__ import annotations
+
+import inspect
+from collections import OrderedDict
+from typing import Any, Dict, Union
+
+import torch
+import yaml
+
+_REGISTRY: Dict[str, type] = {}
+
+
+def _to_config_value(v: Any) -> Any:
+    if isinstance(v, Model):
+        return v.config.as_dict()
+    if isinstance(v, (list, tuple)):
+        return [_to_config_value(i) for i in v]
+    if isinstance(v, slice):
+        return {"__slice__": [v.start, v.stop, v.step]}
+    if isinstance(v, type):
+        return {"__class__": f"{v.__module__}.{v.__qualname__}"}
+    if isinstance(v, dict):
+        return {k: _to_config_value(i) for k, i in v.items()}
+    if isinstance(v, (int, float, str, bool)) or v is None:
+        return v
+    return repr(v)
+
+
+class ModelConfig:
+    """``class_name`` + ``arguments`` (``utilities/config/model_config.py:30-98``)."""
+
+    def __init__(self, class_name: str, arguments: Dict[str, Any]):
+        self.class_name = class_name
+        self.arguments = arguments
+
+    def as_dict(self) -> Dict[str, Any]:
+        return {"class_name": self.class_name, "arguments": _to_config_value(self.arguments)}
+
+    def dump(self, path: str = None) -> str:
+        text = yaml.safe_dump(self.as_dict(), sort_keys=False)
+        if path is not None:
+            with open(path, "w") as f:
+                f.write(text)
+        return text
+
+    @classmethod
+    def load(cls, path: str) -> "ModelConfig":
+        with open(path) as f:
+            d = yaml.safe_load(f)
+        return cls(d["class_name"], d["arguments"])
+
+    @staticmethod
+    def _from_value(v: Any) -> Any:
+        if isinstance(v, dict) and set(v) == {"class_name", "arguments"}:
+            return ModelConfig(v["class_name"], v["arguments"]).construct()
+        if isinstance(v, dict) and set(v) == {"__slice__"}:
+            return slice(*v["__slice__"])
+        if isinstance(v, dict):
+            return {k: ModelConfig._from_value(i) for k, i in v.items()}
+        if isinstance(v, list):
+            return [ModelConfig._from_value(i) for i in v]
+        return v
+
+    def construct(self) -> "Model":
+        """Rebuild by bare class name (``utilities/config/parsing.py:57-73`` looks classes up
+        by name across the package; here every ``Model`` subclass registers itself)."""
+        klass = _REGISTRY[self.class_name]
+        args = {k: self._from_value(v) for k, v in self.arguments.items()}
+        # YAML has no tuples: dynedge_layer_sizes is a list of tuples in the ctor contract
+        if "dynedge_layer_sizes" in args and args["dynedge_layer_sizes"] is not None:
+            args["dynedge_layer_sizes"] = [tuple(s) for s in args["dynedge_layer_sizes"]]
+        return klass(**args)
+
+
+class _ConfigSaverMeta(type):
+    """Captures the actual constructor call + defaults (``model_config.py:317-346``)."""
+
+    def __call__(cls, *args: Any, **kwargs: Any) -> Any:
+        obj = super().__call__(*args, **kwargs)
+        try:
+            sig = inspect.signature(cls.__init__)
+            bound = sig.bind(obj, *args, **kwargs)
+            bound.apply_defaults()
+            arguments = OrderedDict((k, v) for k, v in bound.arguments.items() if k != "self")
+            arguments.pop("kwargs", None)
+        except TypeError:
+            arguments = OrderedDict(kwargs)
+        obj._config = ModelConfig(cls.__name__, dict(arguments))
+        return obj
+
+    def __init__(cls, name, bases, ns):
+        super().__init__(name, bases, ns)
+        _REGISTRY[name] = cls
+
+
+class Model(torch.nn.Module, metaclass=_ConfigSaverMeta):
+    """Base class for all components (``models/model.py:20``)."""
+
+    @property
+    def config(self) -> ModelConfig:
+        return self._config
+
+    def save_config(self, path: str) -> None:
+        self._config.dump(path)
+
+    @classmethod
+    def from_config(cls, source: Union[ModelConfig, str]) -> "Model":
+        if isinstance(source, str):
+            source = ModelConfig.load(source)
+        return source.construct()
+
+    def save_state_dict(self, path: str) -> None:
+        if not path.endswith(".pth"):
+            path += ".pth"
+        torch.save(self.state_dict(), path)
+
+    def load_state_dict(self, path: Union[str, Dict], **kargs: Any) -> "Model":  # type: ignore[override]
+        state_dict = torch.load(path, weights_only=True) if isinstance(path, str) else path
+        state_dict = OrderedDict(
+            (("backbone." + k[len("_gnn."):]) if k.startswith("_gnn.") else k, v) for k, v in state_dict.items())
+        super().load_state_dict(state_dict, **kargs)
+        return self

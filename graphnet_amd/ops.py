@@ -1,0 +1,375 @@
+"""Tensor-level wrappers over the C ABI (``include/graphnet_amd.h``).
+
+PyTorch supplies device memory and the HIP stream; every computation on the DynEdge path is a
+kernel of ``libgraphnet_amd.so``.  All functions require CUDA(HIP) tensors and raise
+``RuntimeError`` if the library is missing — there is no CPU path here by design.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+MODE_F32 = 0
+MODE_BF16 = 1
+POOL_CODES = {"min": 0, "max": 1, "sum": 2, "mean": 3}
+
+
+# ---- optional per-op HIP-event timers (bench.py's live roofline measurement) --------------
+_TIMERS = None
+
+
+def enable_timers(on: bool = True) -> None:
+    """Record a HIP event pair on the launch stream around every C-ABI op."""
+    global _TIMERS
+    _TIMERS = {} if on else None
+
+
+class _timed:
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if _TIMERS is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if _TIMERS is not None:
+            self.ev[1].record()
+            _TIMERS.setdefault(self.name, []).append(self.ev)
+        return False
+
+
+def timer_summary() -> dict:
+    """name -> (launches, total milliseconds); synchronises."""
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (_TIMERS or {}).items()}
+
+
+def mode_dtype(mode: int) -> torch.dtype:
+    return torch.float32 if mode == MODE_F32 else torch.bfloat16
+
+
+def _st() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: Tensor, dtype: torch.dtype, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: graphnet_amd device ops need a HIP tensor (got {t.device}); no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _rows(t: Tensor, name: str) -> int:
+    """Row pitch (elements) of a 2-D tensor whose rows are contiguous."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name}: need a 2-D tensor with unit column stride")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------ graph
+@dataclass
+class NeighbourTable:
+    """One layer's graph: fixed-stride table + overflow list (+ lazily built reverse lists)."""
+
+    nbr: Tensor                 # [N, K] int32, -1 padded
+    ovf: Optional[Tensor]       # [N] int32 (-1 = none) or None in strict mode
+    ovf_centre: Optional[Tensor]
+    ovf_src: Optional[Tensor]
+    ovf_cnt: Optional[Tensor]   # [1] int32 on device
+    K: int
+    rev_ptr: Optional[Tensor] = None
+    rev_rows: Optional[Tensor] = None
+
+    @property
+    def N(self) -> int:
+        return int(self.nbr.shape[0])
+
+    @property
+    def S(self) -> int:
+        return int(_lib.lib().gn_edge_slots(self.K))
+
+    @property
+    def rows(self) -> int:
+        """Upper bound of edge rows (table rows + one overflow row per node)."""
+        return self.N * self.S + self.N
+
+    def c_args(self):
+        return (_p(self.nbr), _p(self.ovf_centre), _p(self.ovf_src), _p(self.ovf_cnt), self.N, self.K)
+
+    def build_reverse(self) -> None:
+        if self.rev_ptr is not None:
+            return
+        L = _lib.lib()
+        N, dev = self.N, self.nbr.device
+        rev_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        cursor = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        tmp = torch.empty(int(L.gn_scan_tmp_ints(N)), dtype=torch.int32, device=dev)
+        rev_rows = torch.empty(max(N * self.K + N, 1), dtype=torch.int32, device=dev)
+        with _timed("rev_build"):
+            _lib.check(L.gn_rev_build(_p(self.nbr), N, self.K, _p(self.ovf_src), _p(self.ovf_cnt), _p(rev_ptr),
+                                      _p(cursor), _p(tmp), _p(rev_rows), _st()))
+        self.rev_ptr, self.rev_rows = rev_ptr, rev_rows
+
+    def edge_index(self) -> Tensor:
+        """Materialise PyG-style ``edge_index[2,E]`` int64 (API boundary only; syncs)."""
+        L = _lib.lib()
+        N, dev = self.N, self.nbr.device
+        deg = torch.empty(N, dtype=torch.int32, device=dev)
+        _lib.check(L.gn_table_degree(_p(self.nbr), _p(self.ovf), N, self.K, _p(deg), _st()))
+        off = torch.empty(N, dtype=torch.int32, device=dev)
+        tot = torch.zeros(1, dtype=torch.int32, device=dev)
+        tmp = torch.empty(int(L.gn_scan_tmp_ints(N)), dtype=torch.int32, device=dev)
+        _lib.check(L.gn_scan_i32(_p(deg), _p(off), N, _p(tmp), _p(tot), _st()))
+        E = int(tot.item())
+        ei = torch.empty((2, E), dtype=torch.int64, device=dev)
+        _lib.check(L.gn_table_to_edge_index(_p(self.nbr), _p(self.ovf), N, self.K, _p(off), E, _p(ei), _st()))
+        return ei
+
+
+def _finish_table(nbr: Tensor, ovf: Optional[Tensor], K: int) -> NeighbourTable:
+    if ovf is None:
+        return NeighbourTable(nbr, None, None, None, None, K)
+    L = _lib.lib()
+    N, dev = int(nbr.shape[0]), nbr.device
+    work = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    tmp = torch.empty(int(L.gn_scan_tmp_ints(N)), dtype=torch.int32, device=dev)
+    oc = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    os_ = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(L.gn_ovf_compact(_p(ovf), N, _p(work), _p(tmp), _p(oc), _p(os_), _p(cnt), _st()))
+    return NeighbourTable(nbr, ovf, oc, os_, cnt, K)
+
+
+def knn_graph(x: Tensor, cols: Sequence[int], batch: Tensor, ptr: Tensor, k: int,
+              strict: bool = False) -> NeighbourTable:
+    """Batched brute-force k-NN on ``x[:, cols]`` (fp32) inside each event."""
+    _need(x, torch.float32, "x"); _need(batch, torch.int32, "batch"); _need(ptr, torch.int32, "ptr")
+    N = int(x.shape[0])
+    ld = _rows(x, "x")
+    nbr = torch.empty((N, k), dtype=torch.int32, device=x.device)
+    ovf = None if strict else torch.empty(max(N, 1), dtype=torch.int32, device=x.device)
+    c = (ctypes.c_int32 * len(cols))(*[int(v) for v in cols])
+    with _timed("knn_graph"):
+        _lib.check(_lib.lib().gn_knn_graph(_p(x), ld, ctypes.cast(c, ctypes.c_void_p), len(cols), _p(batch), _p(ptr),
+                                           N, k, 1 if strict else 0, _p(nbr), _p(ovf), _st()))
+    return _finish_table(nbr, None if strict else ovf[:N] if N else ovf, k)
+
+
+def table_from_edge_index(edge_index: Tensor, N: int, K: int) -> NeighbourTable:
+    """Loader-supplied ``edge_index`` (sorted by target, degree <= K+1) -> neighbour table."""
+    _need(edge_index, torch.int64, "edge_index")
+    edge_index = edge_index.contiguous()
+    dev = edge_index.device
+    E = int(edge_index.shape[1])
+    nbr = torch.empty((N, K), dtype=torch.int32, device=dev)
+    ovf = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    first = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().gn_edge_index_to_table(_p(edge_index), E, N, K, _p(first), _p(nbr), _p(ovf), _p(err), _st()))
+    if int(err.item()) != 0:
+        raise ValueError("edge_index must be grouped by target node (ascending) with in-degree <= K+1")
+    return _finish_table(nbr, ovf[:N] if N else ovf, K)
+
+
+def ptr_to_batch(ptr: Tensor, N: int) -> Tensor:
+    _need(ptr, torch.int32, "ptr")
+    batch = torch.empty(max(N, 1), dtype=torch.int32, device=ptr.device)[:N]
+    _lib.check(_lib.lib().gn_ptr_to_batch(_p(ptr), int(ptr.shape[0]) - 1, _p(batch), _st()))
+    return batch
+
+
+def graph_globals(x: Tensor, ptr: Tensor, g: NeighbourTable, n_pulses: Tensor) -> Tensor:
+    _need(x, torch.float32, "x"); _need(n_pulses, torch.int32, "n_pulses")
+    B, F = int(ptr.shape[0]) - 1, int(x.shape[1])
+    out = torch.empty((B, F + 5), dtype=torch.float32, device=x.device)
+    with _timed("graph_globals"):
+        _lib.check(_lib.lib().gn_graph_globals(_p(x), _rows(x, "x"), F, _p(ptr), B, _p(g.nbr), _p(g.ovf), g.K,
+                                               _p(n_pulses), _p(out), _st()))
+    return out
+
+
+def concat_globals(x: Tensor, gv: Optional[Tensor], batch: Tensor, ld0: int) -> Tensor:
+    """``[x | gv[batch] | 0]`` with row pitch ``ld0`` (a multiple of 32)."""
+    N, F = int(x.shape[0]), int(x.shape[1])
+    G = 0 if gv is None else int(gv.shape[1])
+    x0 = torch.empty((N, ld0), dtype=torch.float32, device=x.device)
+    gvt = gv if gv is not None else x
+    _lib.check(_lib.lib().gn_concat_globals(_p(x), _rows(x, "x"), F, _p(gvt), G, _p(batch), N, _p(x0), ld0, _st()))
+    return x0
+
+
+# ------------------------------------------------------------------------------ dense layers
+Seg = Tuple[Tensor, int]   # (fp32 tensor [M, >=width] with unit column stride, real width)
+
+
+def _seg_arrays(segs: Sequence[Seg], with_kpad: bool):
+    n = len(segs)
+    ptrs = (ctypes.c_void_p * n)(*[s[0].data_ptr() for s in segs])
+    lds = (ctypes.c_int64 * n)(*[_rows(s[0], "segment") for s in segs])
+    widths = (ctypes.c_int32 * n)(*[int(s[1]) for s in segs])
+    kpads = (ctypes.c_int32 * n)(*[round_up(int(s[1]), 32) for s in segs]) if with_kpad else None
+    for s in segs:
+        _need(s[0], torch.float32, "segment")
+    return n, ptrs, lds, widths, kpads
+
+
+def pack_weight(W: Tensor, seg_widths: Sequence[int], dtype: torch.dtype) -> Tensor:
+    """``W[N, sum widths]`` fp32 -> ``[ceil128(N)][sum ceil32(width)]`` of ``dtype`` (zero padded)."""
+    N = int(W.shape[0])
+    parts, off = [], 0
+    for w in seg_widths:
+        blk = W[:, off:off + w]
+        parts.append(torch.nn.functional.pad(blk, (0, round_up(w, 32) - w)))
+        off += w
+    Wp = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
+    Wp = torch.nn.functional.pad(Wp, (0, 0, 0, round_up(N, 128) - N))
+    return Wp.to(dtype).contiguous()
+
+
+def linear_fwd(mode: int, segs: Sequence[Seg], Wp: Tensor, n_real: int, bias: Optional[Tensor] = None,
+               relu: bool = False, gate: Optional[Tensor] = None, out: Optional[Tensor] = None,
+               accum: bool = False, out_lowp: bool = False, out_cols: Optional[int] = None) -> Tensor:
+    """``out[M, n_real] = epi(cat(segs) @ W^T + bias)`` on MFMA.  ``Wp`` from :func:`pack_weight`."""
+    n, ptrs, lds, widths, kpads = _seg_arrays(segs, True)
+    M = int(segs[0][0].shape[0])
+    Npad, Kp = int(Wp.shape[0]), int(Wp.shape[1])
+    if out is None:
+        cols = out_cols if out_cols is not None else n_real
+        out = torch.empty((M, cols), dtype=mode_dtype(mode) if out_lowp else torch.float32, device=Wp.device)
+        if cols > n_real:
+            out[:, n_real:].zero_()
+    with _timed("linear_fwd"):
+        _lib.check(_lib.lib().gn_linear_fwd(
+            mode, n, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(lds, ctypes.c_void_p),
+            ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(kpads, ctypes.c_void_p), M, _p(Wp), Kp, Npad, n_real,
+            _p(bias), _p(gate), 0 if gate is None else _rows(gate, "gate"), int(relu), int(accum),
+            _p(out), _rows(out, "out"), int(out_lowp), _st()))
+    return out
+
+
+def linear_wgrad(mode: int, dY: Tensor, n1: int, segs: Sequence[Seg], out: Optional[Tensor] = None,
+                 accum: bool = False) -> Tensor:
+    """``dW[n1, sum widths] (+)= dY[:, :n1]^T @ cat(segs)`` (deterministic split reduction)."""
+    _need(dY, torch.float32, "dY")
+    n, ptrs, lds, widths, _ = _seg_arrays(segs, False)
+    M = int(dY.shape[0])
+    ktot = sum(int(s[1]) for s in segs)
+    L = _lib.lib()
+    splits = int(L.gn_linear_wgrad_splits(M))
+    slab = torch.empty(splits * n1 * ktot, dtype=torch.float32, device=dY.device)
+    if out is None:
+        out = torch.empty((n1, ktot), dtype=torch.float32, device=dY.device)
+    with _timed("linear_wgrad"):
+        _lib.check(L.gn_linear_wgrad(mode, _p(dY), _rows(dY, "dY"), n1, n, ctypes.cast(ptrs, ctypes.c_void_p),
+                                     ctypes.cast(lds, ctypes.c_void_p), ctypes.cast(widths, ctypes.c_void_p), M,
+                                     _p(slab), _p(out), int(accum), _st()))
+    return out
+
+
+def colsum(X: Tensor, C: int, out: Optional[Tensor] = None, accum: bool = False) -> Tensor:
+    _need(X, torch.float32, "X")
+    L = _lib.lib()
+    M = int(X.shape[0])
+    part = torch.empty(int(L.gn_colsum_blocks(M)) * C, dtype=torch.float32, device=X.device)
+    if out is None:
+        out = torch.empty(C, dtype=torch.float32, device=X.device)
+    with _timed("colsum"):
+        _lib.check(L.gn_colsum(_p(X), _rows(X, "X"), M, C, _p(part), _p(out), int(accum), _st()))
+    return out
+
+
+# ------------------------------------------------------------------------------ EdgeConv
+def edgeconv_fwd(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, W2p: Tensor, b2: Tensor, H2: int,
+                 out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """``out[i] = sum_j relu(relu(P[i]+Q[j]) W2^T + b2)``; returns (out fp32 [N,H2], relu bit mask)."""
+    _need(PQ, mode_dtype(mode), "PQ"); _need(W2p, mode_dtype(mode), "W2p"); _need(b2, torch.float32, "b2")
+    N = g.N
+    if out is None:
+        out = torch.empty((N, H2), dtype=torch.float32, device=PQ.device)
+    mask = torch.empty(max(g.rows, 1) * ((H2 + 31) // 32), dtype=torch.int32, device=PQ.device)
+    with _timed("edgeconv_fwd"):
+        _lib.check(_lib.lib().gn_edgeconv_fwd(mode, *g.c_args(), _p(PQ), H1p, _p(W2p), _p(b2), H2, _p(out),
+                                              _rows(out, "out"), _p(mask), _st()))
+    return out, mask
+
+
+def edgeconv_bwd(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, H2: int, gout: Tensor, mask: Tensor,
+                 W2Tp: Tensor, dpre: Tensor, dP: Tensor) -> None:
+    _need(gout, torch.float32, "gout"); _need(dP, torch.float32, "dP")
+    with _timed("edgeconv_bwd"):
+        _lib.check(_lib.lib().gn_edgeconv_bwd(mode, *g.c_args(), _p(PQ), H1p, H2, _p(gout), _rows(gout, "gout"),
+                                              _p(mask), _p(W2Tp), int(W2Tp.shape[1]), _p(dpre), _p(dP),
+                                              _rows(dP, "dP"), _st()))
+
+
+def edgeconv_dw2(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, H1: int, H2: int, gout: Tensor,
+                 mask: Tensor) -> Tuple[Tensor, Tensor]:
+    """Returns (dW2 [H2, H1], db2 [H2])."""
+    L = _lib.lib()
+    splits = int(L.gn_edgeconv_dw2_splits(g.rows))
+    dev = PQ.device
+    slab = torch.empty(splits * H2 * H1, dtype=torch.float32, device=dev)
+    bpart = torch.empty(splits * H2, dtype=torch.float32, device=dev)
+    with _timed("edgeconv_dw2"):
+        _lib.check(L.gn_edgeconv_dw2(mode, *g.c_args(), _p(PQ), H1p, H1, H2, _p(gout), _rows(gout, "gout"), _p(mask),
+                                     _p(slab), _p(bpart), splits, _st()))
+    dW2 = torch.empty((H2, H1), dtype=torch.float32, device=dev)
+    db2 = torch.empty(H2, dtype=torch.float32, device=dev)
+    _lib.check(L.gn_reduce_slabs(_p(slab), splits, H2 * H1, _p(dW2), 0, _st()))
+    _lib.check(L.gn_reduce_slabs(_p(bpart), splits, H2, _p(db2), 0, _st()))
+    return dW2, db2
+
+
+def edgeconv_dq_gather(mode: int, g: NeighbourTable, dpre: Tensor, H1p: int, dQ: Tensor) -> None:
+    g.build_reverse()
+    with _timed("edgeconv_dq_gather"):
+        _lib.check(_lib.lib().gn_edgeconv_dq_gather(mode, _p(dpre), H1p, _p(g.rev_ptr), _p(g.rev_rows), g.N, _p(dQ),
+                                                    _rows(dQ, "dQ"), _st()))
+
+
+# ------------------------------------------------------------------------------ pooling
+def _codes(schemes: Sequence[str]):
+    return (ctypes.c_int32 * len(schemes))(*[POOL_CODES[s] for s in schemes])
+
+
+def segment_pool_fwd(x: Tensor, C: int, ptr: Tensor, schemes: Sequence[str], need_arg: bool = True):
+    _need(x, torch.float32, "x")
+    B = int(ptr.shape[0]) - 1
+    out = torch.empty((B, len(schemes) * C), dtype=torch.float32, device=x.device)
+    amin = torch.empty((B, C), dtype=torch.int32, device=x.device) if need_arg else None
+    amax = torch.empty((B, C), dtype=torch.int32, device=x.device) if need_arg else None
+    c = _codes(schemes)
+    with _timed("segment_pool_fwd"):
+        _lib.check(_lib.lib().gn_segment_pool_fwd(_p(x), _rows(x, "x"), C, _p(ptr), B, ctypes.cast(c, ctypes.c_void_p),
+                                                  len(schemes), _p(out), _p(amin), _p(amax), _st()))
+    return out, amin, amax
+
+
+def segment_pool_bwd(gout: Tensor, C: int, ptr: Tensor, batch: Tensor, N: int, schemes: Sequence[str],
+                     amin: Tensor, amax: Tensor, gate: Optional[Tensor]) -> Tensor:
+    gout = gout.contiguous()
+    _need(gout, torch.float32, "gout")
+    dx = torch.empty((N, C), dtype=torch.float32, device=gout.device)
+    c = _codes(schemes)
+    with _timed("segment_pool_bwd"):
+        _lib.check(_lib.lib().gn_segment_pool_bwd(_p(gout), C, _p(ptr), _p(batch), N, ctypes.cast(c, ctypes.c_void_p),
+                                                  len(schemes), _p(amin), _p(amax), _p(gate),
+                                                  0 if gate is None else _rows(gate, "gate"), _p(dx), C, _st()))
+    return dx

@@ -1,0 +1,77 @@
+"""Event-batch data parallelism: one process per GPU, one flat gradient all-reduce per step.
+
+The reference delegates this to Lightning ``Trainer(strategy="ddp")``
+(``models/easy_model.py:83-112``): event batches are sharded across ranks, the model is
+replicated, gradients are summed with NCCL.  Here: the model is 5.5 MB, so
+the exchange is latency-bound — all parameter gradients live in ONE flat fp32 buffer (the
+``.grad`` tensors are views into it) and a single RCCL all-reduce over xGMI moves it after the
+last backward kernel.  Works unchanged with the ``gloo`` backend on CPU tensors (tests).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+class FlatGradAllReduce:
+    """Keeps every parameter's ``.grad`` as a view of one flat buffer and all-reduces it."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], average: bool = True, group=None):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.average = average
+        self.group = group
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self.views = []
+        for p in self.params:
+            v = self.flat[off: off + p.numel()].view_as(p)
+            p.grad = v
+            self.views.append(v)
+            off += p.numel()
+
+    def zero_grad(self) -> None:
+        """Use instead of ``optimizer.zero_grad(set_to_none=True)`` so the views survive."""
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def __call__(self) -> None:
+        # autograd may have replaced .grad (first accumulation) -> copy back into the flat buffer
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+                p.grad = v
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                self.flat.div_(dist.get_world_size(self.group))
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Identical initial weights on every rank (what DDP does at construction)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+def shard_events_by_pulses(n_pulses: Sequence[int], world_size: int) -> List[List[int]]:
+    """Greedy longest-first assignment of events to ranks balancing total pulses (cost ~ N),
+    in the spirit of ``data/dataset/samplers.py:160-292`` (length-matched batches)."""
+    order = sorted(range(len(n_pulses)), key=lambda i: -int(n_pulses[i]))
+    loads = [0] * world_size
+    shards: List[List[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda j: loads[j])
+        shards[r].append(i)
+        loads[r] += int(n_pulses[i])
+    for s in shards:
+        s.sort()
+    return shards

@@ -46,7 +46,11 @@ def icecube86_geometry() -> np.ndarray:
     if _GEO is None:
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                             "tests", "golden", "icecube86_geometry.npz")
-        _GEO = np.load(path)["table"] if os.path.exists(path) else _analytic_geometry()
+        geo = np.load(path)["table"] if os.path.exists(path) else _analytic_geometry()
+        # in-ice sensors only: the table also lists 324 IceTop tanks (z ~ +1950 m) and 3 rows
+        # without a relative efficiency (NaN), which real in-ice pulse series never contain
+        keep = np.isfinite(geo).all(1) & (geo[:, 2] < 600.0)
+        _GEO = np.ascontiguousarray(geo[keep])
     return _GEO
 
 

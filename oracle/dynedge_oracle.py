@@ -340,7 +340,9 @@ class DynEdgeOracle(torch.nn.Module):
         return torch.cat([means, hx, hy, hz, ht, logn], dim=1)
 
     def forward(self, x: Tensor, edge_index: Tensor, batch: Tensor, n_pulses: Tensor,
-                return_trace: bool = False):
+                return_trace: bool = False, forced_edges: Optional[List[Tensor]] = None):
+        """``forced_edges[l]`` (optional) replaces the re-kNN result used by conv layer l >= 1
+        (teacher forcing for per-layer parity checks; the reference always recomputes)."""
         num_graphs = int(n_pulses.shape[0])
         trace = {}
         gv = self.global_variables(x, edge_index, batch, n_pulses, num_graphs)
@@ -354,10 +356,13 @@ class DynEdgeOracle(torch.nn.Module):
             x = torch.cat((x, gvd), dim=1)
         skips = [x]
         trace["edge_index"] = [edge_index]
-        for conv in self._conv_layers:
+        for l, conv in enumerate(self._conv_layers):
             x = edge_conv(x, edge_index, conv.nn, "add")
-            edge_index = knn_graph(x, self._nb_neighbours, batch, self._features_subset,
-                                   self._knn_mode)
+            if forced_edges is not None and l + 1 < len(forced_edges):
+                edge_index = forced_edges[l + 1]
+            else:
+                edge_index = knn_graph(x, self._nb_neighbours, batch, self._features_subset,
+                                       self._knn_mode)
             skips.append(x)
             trace["edge_index"].append(edge_index)
         trace["conv_out"] = skips
@@ -401,13 +406,25 @@ def piecewise_linear_factor(step: int, milestones: Sequence[int], factors: Seque
     return float(np.interp(step, milestones, factors))
 
 
+class _TaskHolder(torch.nn.Module):
+    """Gives the head the reference's key ``_tasks.0._affine.*`` (task.py:251)."""
+
+    def __init__(self, hidden_size: int):
+        super().__init__()
+        self._affine = torch.nn.Linear(hidden_size, 1)
+
+
 class StandardModelOracle(torch.nn.Module):
     """DynEdge + EnergyReconstruction + LogCosh (standard_model.py:71-119) on CPU."""
 
     def __init__(self, nb_inputs: int = 7, **dynedge_kwargs):
         super().__init__()
         self.backbone = DynEdgeOracle(nb_inputs, **dynedge_kwargs)
-        self._affine = torch.nn.Linear(self.backbone._nb_outputs, 1)
+        self._tasks = torch.nn.ModuleList([_TaskHolder(self.backbone._nb_outputs)])
+
+    @property
+    def _affine(self) -> torch.nn.Linear:
+        return self._tasks[0]._affine
 
     def forward(self, x, edge_index, batch, n_pulses):
         latent = self.backbone(x, edge_index, batch, n_pulses)

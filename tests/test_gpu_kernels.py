@@ -1,0 +1,281 @@
+"""GPU parity tests: every kernel of the C ABI against the CPU oracle (same seeded inputs).
+
+Integer/index results must be bit-exact; fp32 mode within 1e-4 relative (of the tensor's max
+magnitude); bf16 operand mode within 2e-2 (stated in each assert).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+MODES = [("fp32", 0, 1e-4), ("bf16", 1, 2e-2)]
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _batch(n_events=12, seed=3):
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    return synthetic_icecube86_batch(n_events, seed=seed)
+
+
+def _csr(b):
+    ptr32 = b.ptr.to(torch.int32).to(DEV)
+    batch32 = b.batch.to(torch.int32).to(DEV)
+    return ptr32, batch32
+
+
+def _oracle_table(oracle, x, ptr, k, cols, mode):
+    nbr, _ = oracle.knn_table(x, k, ptr.long(), cols, mode)
+    return nbr
+
+
+def _cmp_table(table, nbr_oracle, k):
+    got = table.nbr.cpu().numpy()
+    exp = nbr_oracle.numpy()
+    assert np.array_equal(got, exp[:, :k])
+    if table.ovf is not None:
+        assert np.array_equal(table.ovf.cpu().numpy(), exp[:, k])
+        cnt = int(table.ovf_cnt.item())
+        centres = np.nonzero(exp[:, k] >= 0)[0]
+        assert cnt == len(centres)
+        assert np.array_equal(table.ovf_centre.cpu().numpy()[:cnt], centres)
+        assert np.array_equal(table.ovf_src.cpu().numpy()[:cnt], exp[centres, k])
+
+
+# ------------------------------------------------------------------------------ k-NN
+@pytest.mark.parametrize("mode", ["compat", "strict"])
+@pytest.mark.parametrize("k", [8, 16, 3])
+def test_knn_bit_exact_synthetic(oracle, mode, k):
+    from graphnet_amd import ops
+    b = _batch(40, seed=11)
+    ptr32, batch32 = _csr(b)
+    t = ops.knn_graph(b.x.to(DEV), [0, 1, 2], batch32, ptr32, k, strict=(mode == "strict"))
+    _cmp_table(t, _oracle_table(oracle, b.x, b.ptr, k, [0, 1, 2], mode), k)
+
+
+def test_knn_reference_events_and_edge_index(oracle, golden):
+    from graphnet_amd import ops
+    ex, ev = golden["oracle_expected"], golden["reference_events"]
+    for name in ("deepcore", "upgrade", "prometheus"):
+        x = torch.from_numpy(ex[f"{name}_xstd"])
+        ptr = torch.from_numpy(ev[f"{name}_ptr"])
+        n = (ptr[1:] - ptr[:-1])
+        batch32 = torch.repeat_interleave(torch.arange(len(n)), n).to(torch.int32).to(DEV)
+        for mode in ("compat", "strict"):
+            t = ops.knn_graph(x.to(DEV), [0, 1, 2], batch32, ptr.to(torch.int32).to(DEV), 8, strict=(mode == "strict"))
+            exp = torch.from_numpy(ex[f"{name}_nbr_{mode}"])
+            _cmp_table(t, exp, 8)
+            ei = t.edge_index().cpu()
+            assert torch.equal(ei, oracle.table_to_edge_index(exp))
+            if mode == "compat":       # loader edge_index -> table round trip
+                t2 = ops.table_from_edge_index(ei.to(DEV), x.shape[0], 8)
+                _cmp_table(t2, exp, 8)
+
+
+def test_knn_edge_cases(oracle):
+    from graphnet_amd import ops
+    # ragged: events of 1, 2, 3 nodes (degree n-1), > k duplicates, D = 4 columns, big event
+    rng = np.random.default_rng(5)
+    sizes = [1, 2, 3, 30, 1500, 9, 2]
+    x = rng.normal(size=(sum(sizes), 6)).astype(np.float32)
+    x[40:60, :4] = x[39, :4]
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64)
+    n = ptr[1:] - ptr[:-1]
+    batch32 = torch.repeat_interleave(torch.arange(len(n)), n).to(torch.int32).to(DEV)
+    xt = torch.from_numpy(x)
+    for cols in ([0, 1, 2], [0, 1, 2, 3], [5, 1]):
+        t = ops.knn_graph(xt.to(DEV), cols, batch32, ptr.to(torch.int32).to(DEV), 8)
+        _cmp_table(t, _oracle_table(oracle, xt, ptr, 8, cols, "compat"), 8)
+    # strided view (latent features are a column slice of a wider row)
+    wide = torch.zeros(x.shape[0], 64)
+    wide[:, 10:16] = xt
+    t = ops.knn_graph(wide.to(DEV)[:, 10:16], [0, 1, 2], batch32, ptr.to(torch.int32).to(DEV), 8)
+    _cmp_table(t, _oracle_table(oracle, xt, ptr, 8, [0, 1, 2], "compat"), 8)
+
+
+def test_reverse_adjacency(oracle):
+    from graphnet_amd import ops
+    b = _batch(10, seed=2)
+    x = b.x.clone()
+    x[5:20, :3] = x[4, :3]                      # force overflow rows
+    ptr32, batch32 = _csr(b)
+    t = ops.knn_graph(x.to(DEV), [0, 1, 2], batch32, ptr32, 8)
+    t.build_reverse()
+    N, K, S = t.N, 8, t.S
+    nbr = t.nbr.cpu().numpy()
+    cnt = int(t.ovf_cnt.item())
+    assert cnt > 0
+    osrc = t.ovf_src.cpu().numpy()[:cnt]
+    rp, rr = t.rev_ptr.cpu().numpy(), t.rev_rows.cpu().numpy()
+    exp = [[] for _ in range(N)]
+    for i in range(N):
+        for s in range(K):
+            if nbr[i, s] >= 0:
+                exp[nbr[i, s]].append(i * S + s)
+    for q in range(cnt):
+        exp[osrc[q]].append(N * S + q)
+    assert rp[0] == 0 and rp[N] == sum(len(e) for e in exp)
+    for j in range(N):
+        assert sorted(rr[rp[j]:rp[j + 1]].tolist()) == sorted(exp[j])
+
+
+# ------------------------------------------------------------------------------ globals
+def test_graph_globals(oracle):
+    from graphnet_amd import ops
+    b = _batch(25, seed=4)
+    ptr32, batch32 = _csr(b)
+    t = ops.knn_graph(b.x.to(DEV), [0, 1, 2], batch32, ptr32, 8)
+    gv = ops.graph_globals(b.x.to(DEV), ptr32, t, b.n_pulses.to(DEV)).cpu()
+    ei = oracle.knn_graph(b.x, 8, b.batch, [0, 1, 2])
+    m = oracle.DynEdgeOracle(7)
+    exp = m.global_variables(b.x, ei, b.batch, b.n_pulses, len(b.n_pulses))
+    assert torch.equal(gv[:, 7:11], exp[:, 7:11])             # homophily: integer counts -> exact
+    assert (gv[:, 7:11] > 0).any()
+    assert torch.allclose(gv, exp, rtol=1e-5, atol=1e-6)
+    x0 = ops.concat_globals(b.x.to(DEV), gv.to(DEV), batch32, 32).cpu()
+    assert torch.equal(x0[:, :7], b.x) and torch.equal(x0[:, 7:19], gv[b.batch]) and (x0[:, 19:] == 0).all()
+
+
+# ------------------------------------------------------------------------------ dense layers
+@pytest.mark.parametrize("name,mode,tol", MODES)
+def test_linear_fwd_segments_and_epilogues(name, mode, tol):
+    from graphnet_amd import ops
+    torch.manual_seed(0)
+    M = 1000
+    widths = [19, 256, 64]
+    xs = [torch.randn(M, ops.round_up(w, 32)) for w in widths]
+    for x, w in zip(xs, widths):
+        x[:, w:] = 0
+    W = torch.randn(336, sum(widths)) * 0.1
+    bias = torch.randn(336)
+    ref = torch.cat([x[:, :w] for x, w in zip(xs, widths)], 1) @ W.t() + bias
+    segs = [(x.to(DEV), w if w % 4 == 0 else ops.round_up(w, 32)) for x, w in zip(xs, widths)]
+    # the 19-wide segment is passed zero-padded to 32 columns: pack W accordingly
+    Wfull = torch.zeros(336, sum(s[1] for s in segs))
+    off = offp = 0
+    for (x, wp), w in zip(segs, widths):
+        Wfull[:, offp:offp + w] = W[:, off:off + w]
+        off += w; offp += wp
+    Wp = ops.pack_weight(Wfull.to(DEV), [s[1] for s in segs], ops.mode_dtype(mode))
+    y = ops.linear_fwd(mode, segs, Wp, 336, bias=bias.to(DEV))
+    assert rel_err(y, ref) < tol, f"{name}: plain"
+    y = ops.linear_fwd(mode, segs, Wp, 336, bias=bias.to(DEV), relu=True)
+    assert rel_err(y, ref.relu()) < tol, f"{name}: relu"
+    gate = torch.randn(M, 336)
+    y = ops.linear_fwd(mode, segs, Wp, 336, bias=bias.to(DEV), gate=gate.to(DEV))
+    assert rel_err(y, ref * (gate > 0)) < tol, f"{name}: gate"
+    base = torch.randn(M, 400)
+    out = base.clone().to(DEV)
+    ops.linear_fwd(mode, segs, Wp, 336, bias=bias.to(DEV), out=out[:, 32:368], accum=True)
+    exp = base.clone(); exp[:, 32:368] += ref
+    assert rel_err(out, exp) < tol, f"{name}: accumulate into a strided view"
+    if mode == 1:
+        y = ops.linear_fwd(mode, segs, Wp, 336, bias=bias.to(DEV), out_lowp=True)
+        assert y.dtype == torch.bfloat16 and rel_err(y.float(), ref) < tol
+
+
+@pytest.mark.parametrize("name,mode,tol", MODES)
+def test_linear_wgrad_and_colsum(name, mode, tol):
+    from graphnet_amd import ops
+    torch.manual_seed(1)
+    M = 5000
+    dY = torch.randn(M, 336)
+    xa, xb = torch.randn(M, 32), torch.randn(M, 256)
+    xa[:, 19:] = 0
+    ref = dY.t() @ torch.cat([xa, xb], 1)
+    dW = ops.linear_wgrad(mode, dY.to(DEV), 336, [(xa.to(DEV), 32), (xb.to(DEV), 256)])
+    assert rel_err(dW, ref) < tol
+    dW2 = ops.linear_wgrad(mode, dY.to(DEV), 336, [(xa.to(DEV), 32), (xb.to(DEV), 256)])
+    assert torch.equal(dW, dW2), "split reduction must be bitwise reproducible"
+    cs = ops.colsum(dY.to(DEV), 336)
+    assert rel_err(cs, dY.sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------ EdgeConv
+def _edgeconv_case(oracle, k=8, F=32, H1=336, H2=256, n_events=14, seed=6, dup=True):
+    b = _batch(n_events, seed=seed)
+    x3 = b.x.clone()
+    if dup:
+        x3[3:16, :3] = x3[2, :3]               # > k duplicates -> overflow rows
+    torch.manual_seed(seed)
+    N = x3.shape[0]
+    x = torch.randn(N, F)
+    mlp = torch.nn.Sequential(torch.nn.Linear(2 * F, H1), torch.nn.ReLU(), torch.nn.Linear(H1, H2), torch.nn.ReLU())
+    ei = oracle.knn_graph(x3, k, b.batch, [0, 1, 2])
+    return b, x3, x, mlp, ei
+
+
+@pytest.mark.parametrize("name,mode,tol", MODES)
+@pytest.mark.parametrize("k,F,H1,H2", [(8, 32, 336, 256), (8, 256, 336, 256), (16, 64, 128, 256), (5, 32, 100, 96)])
+def test_edgeconv_forward(oracle, name, mode, tol, k, F, H1, H2):
+    from graphnet_amd import ops
+    b, x3, x, mlp, ei = _edgeconv_case(oracle, k=k, F=F, H1=H1, H2=H2)
+    ref = oracle.edge_conv(x, ei, mlp, "add").detach()
+    ptr32, batch32 = _csr(b)
+    t = ops.knn_graph(x3.to(DEV), [0, 1, 2], batch32, ptr32, k)
+    assert int(t.ovf_cnt.item()) > 0
+    dt = ops.mode_dtype(mode)
+    W1, b1, W2, b2 = [p.detach().to(DEV) for p in (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)]
+    H1p = ops.round_up(H1, 32)
+    Wpq = torch.zeros(2 * H1p, F, device=DEV)
+    Wpq[:H1] = W1[:, :F] - W1[:, F:]
+    Wpq[H1p:H1p + H1] = W1[:, F:]
+    bpq = torch.zeros(2 * H1p, device=DEV); bpq[:H1] = b1
+    PQ = ops.linear_fwd(mode, [(x.to(DEV), F)], ops.pack_weight(Wpq, [F], dt), 2 * H1p, bias=bpq, out_lowp=(mode == 1))
+    out, _mask = ops.edgeconv_fwd(mode, t, PQ, H1p, ops.pack_weight(W2, [H1], dt), b2, H2)
+    assert rel_err(out, ref) < tol, name
+
+
+@pytest.mark.parametrize("name,mode,tol", MODES)
+def test_single_layer_model_forward_backward(oracle, name, mode, tol):
+    """One DynEdgeConv + post MLP + 4-way pooling + readout, fwd and all gradients."""
+    import graphnet_amd as g
+    b = _batch(9, seed=8)
+    b.x[3:16, :3] = b.x[2, :3]
+    kw = dict(dynedge_layer_sizes=[(128, 256)], global_pooling_schemes=["min", "max", "mean", "sum"])
+    torch.manual_seed(3)
+    ref = oracle.DynEdgeOracle(7, **kw)
+    ei = oracle.knn_graph(b.x, 8, b.batch, [0, 1, 2])
+    yo = ref(b.x, ei, b.batch, b.n_pulses)
+    w = torch.randn_like(yo)
+    (yo * w).sum().backward()
+    m = g.DynEdge(7, **kw)
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).set_backend(dtype=name)
+    y = m(b.to(DEV))
+    (y * w.to(DEV)).sum().backward()
+    assert rel_err(y, yo.detach()) < tol
+    gtol = 1e-3 if mode == 0 else 5e-2
+    for (kn, p), (_, po) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, kn
+        assert rel_err(p.grad, po.grad) < gtol, f"{name}: grad {kn}"
+
+
+# ------------------------------------------------------------------------------ pooling
+def test_segment_pool_forward_backward(oracle):
+    from graphnet_amd import ops
+    torch.manual_seed(2)
+    sizes = [5, 1, 40, 0, 17]
+    N = sum(sizes)
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    x = torch.randn(N, 256).relu().requires_grad_()
+    schemes = ["min", "max", "mean", "sum"]
+    ref = torch.cat([oracle.GLOBAL_POOLINGS[s](x, batch, len(sizes)) for s in schemes], 1)
+    out, amin, amax = ops.segment_pool_fwd(x.detach().to(DEV), 256, ptr.to(DEV), schemes)
+    assert torch.allclose(out.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    assert (out.cpu()[3] == 0).all()                            # empty segment -> 0
+    # backward on strictly positive rows (unique arg): compare with autograd through the oracle
+    x2 = (torch.rand(N, 256) + 0.1).requires_grad_()
+    ref2 = torch.cat([oracle.GLOBAL_POOLINGS[s](x2, batch, len(sizes)) for s in schemes], 1)
+    gw = torch.randn_like(ref2)
+    (ref2 * gw).sum().backward()
+    out2, amin, amax = ops.segment_pool_fwd(x2.detach().to(DEV), 256, ptr.to(DEV), schemes)
+    dx = ops.segment_pool_bwd(gw.to(DEV), 256, ptr.to(DEV), batch.to(torch.int32).to(DEV), N, schemes, amin, amax,
+                              x2.detach().to(DEV))
+    assert torch.allclose(dx.cpu(), x2.grad, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,170 @@
+"""GPU parity tests of the whole DynEdge path (4 DynEdgeConv layers, post MLP, pooling, readout,
+energy head, LogCosh) against the CPU oracle, forward and backward.
+
+The in-model re-kNN is discontinuous in its inputs (a 1-ulp difference in a latent coordinate
+can swap two near-tied neighbours), so the layer-by-layer comparison is *teacher-forced*: the
+oracle is fed the HIP path's neighbour tables, which are themselves checked bit-exact against
+the oracle's k-NN on the same latent coordinates.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _pair(oracle, F=7, seed=20241016, **kw):
+    import graphnet_amd as g
+    torch.manual_seed(seed)
+    ref = oracle.StandardModelOracle(F, **kw)
+    m = g.StandardModel(
+        graph_definition=g.KNNGraph(g.IceCube86()),
+        backbone=g.DynEdge(F, **kw),
+        tasks=[g.EnergyReconstruction(hidden_size=128, loss_function=g.LogCoshLoss(),
+                                      transform_prediction_and_target=torch.log10)],
+        optimizer_kwargs={"lr": 1e-3, "eps": 1e-3},
+    )
+    m.load_state_dict(ref.state_dict())
+    return ref, m.to(DEV)
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [("fp32", 1e-4, 2e-3), ("bf16", 3e-2, 8e-2)])
+def test_full_model_teacher_forced(oracle, dtype, tol, gtol):
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    b = synthetic_icecube86_batch(16, seed=77)
+    kw = dict(global_pooling_schemes=["min", "max", "mean", "sum"])
+    ref, m = _pair(oracle, **kw)
+    m.backbone.set_backend(dtype=dtype)
+    latent, trace = m.backbone(b.to(DEV), return_trace=True)
+    pred = m._tasks[0](latent)
+    loss = m._tasks[0].compute_loss(pred, {"energy": b.energy})
+    loss.backward()
+
+    bc = b.to("cpu")
+    forced = [t.edge_index().cpu() for t in trace["graphs"]]
+    # (1) every neighbour table is bit-exact the oracle's k-NN of the coordinates it was built from
+    assert torch.equal(forced[0], oracle.knn_graph(bc.x, 8, bc.batch, [0, 1, 2]))
+    for l in range(1, 4):
+        coords = trace["conv_out"][l].cpu()
+        assert torch.equal(forced[l], oracle.knn_graph(coords, 8, bc.batch, slice(0, 3)))
+    # (2) teacher-forced layer-by-layer parity
+    lat_o, tr_o = ref.backbone(bc.x, forced[0], bc.batch, bc.n_pulses, return_trace=True, forced_edges=forced)
+    assert rel_err(trace["global_variables"], tr_o["global_variables"]) < 1e-5
+    for l in range(5):
+        w = tr_o["conv_out"][l].shape[1]
+        assert rel_err(trace["conv_out"][l][:, :w], tr_o["conv_out"][l].detach()) < tol, f"conv_out[{l}]"
+    assert rel_err(trace["post"], tr_o["post"].detach()) < tol
+    assert rel_err(latent, lat_o.detach()) < tol
+    pred_o = oracle.energy_reconstruction(lat_o, ref._affine)
+    loss_o = oracle.log_cosh_loss(pred_o, torch.log10(bc.energy).unsqueeze(1))
+    loss_o.backward()
+    assert rel_err(pred, pred_o.detach()) < tol
+    assert abs(float(loss) - float(loss_o)) / abs(float(loss_o)) < tol
+    go = dict(ref.named_parameters())
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        assert rel_err(p.grad, go[k].grad) < gtol, f"{dtype}: grad {k}"
+    # (3) free-running oracle: how many neighbour rows agree (reported, loose gate)
+    if dtype == "fp32":
+        _, tr_free = ref.backbone(bc.x, forced[0], bc.batch, bc.n_pulses, return_trace=True)
+        for l in range(1, 4):
+            a = oracle.knn_table(tr_free["conv_out"][l].detach(), 8, bc.ptr, slice(0, 3))[0]
+            t = trace["graphs"][l]
+            mine = torch.cat([t.nbr.cpu(), t.ovf.cpu().unsqueeze(1)], 1)
+            agree = float((a == mine).all(1).float().mean())
+            assert agree > 0.97, f"layer {l}: only {agree:.4f} of neighbour rows agree with the free-running oracle"
+
+
+def test_config1_prometheus_batch2_against_golden(oracle, golden):
+    """BASELINE configs[0]: DynEdge on the bundled Prometheus events, batch = 2 (fixture from
+    tests/golden/make_fixtures.py; expected values are the oracle's)."""
+    import graphnet_amd as g
+    ex = golden["oracle_expected"]
+    x = torch.from_numpy(ex["prometheus_model_x"])
+    ptr = torch.from_numpy(ex["prometheus_model_ptr"])
+    n = (ptr[1:] - ptr[:-1]).to(torch.int32)
+    b = g.Batch(x=x)
+    b.ptr, b.n_pulses = ptr, n
+    b.batch = torch.repeat_interleave(torch.arange(len(n)), n.long())
+    b.energy = torch.from_numpy(ex["prometheus_model_energy"])
+    torch.manual_seed(20241016)
+    ref = oracle.StandardModelOracle(4, global_pooling_schemes=["min", "max", "mean", "sum"])
+    _, m = _pair(oracle, F=4, global_pooling_schemes=["min", "max", "mean", "sum"])
+    m.load_state_dict(ref.state_dict())
+    m.backbone.set_backend(dtype="fp32")
+    loss = m.shared_step(b.to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(ex["prometheus_model_loss"])) / abs(float(ex["prometheus_model_loss"])) < 1e-3
+    for k, p in m.named_parameters():
+        gn = float(ex[f"prometheus_gradnorm::{k}"])
+        assert abs(float(p.grad.double().norm()) - gn) <= 5e-3 * max(gn, 1e-6), k
+
+
+def test_training_step_decreases_loss_and_is_reproducible():
+    import graphnet_amd as g
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    b = synthetic_icecube86_batch(32, seed=5).to(DEV)
+
+    def run():
+        torch.manual_seed(0)
+        m = g.StandardModel(
+            graph_definition=g.KNNGraph(g.IceCube86()),
+            backbone=g.DynEdge(7, global_pooling_schemes=["min", "max", "mean", "sum"]),
+            tasks=[g.EnergyReconstruction(hidden_size=128, loss_function=g.LogCoshLoss(),
+                                          transform_prediction_and_target=torch.log10)],
+            optimizer_kwargs={"lr": 1e-3, "eps": 1e-3},
+            scheduler_class=g.PiecewiseLinearLR,
+            scheduler_kwargs={"milestones": [0, 5, 20], "factors": [1e-2, 1, 1e-2]},
+        ).to(DEV)
+        opt, sched = m.configure_optimizers()
+        losses = []
+        for _ in range(12):
+            loss = m.shared_step(b)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step(); sched.step()
+            losses.append(float(loss))
+        return losses, [p.detach().clone() for p in m.parameters()]
+
+    l1, p1 = run()
+    l2, p2 = run()
+    assert l1[-1] < l1[0]
+    assert l1 == l2, "no atomics on the path: two runs must be bitwise identical"
+    assert all(torch.equal(a, c) for a, c in zip(p1, p2))
+
+
+def test_node_level_and_globals_after_pooling_variants(oracle):
+    import graphnet_amd as g
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    b = synthetic_icecube86_batch(6, seed=9)
+    ei = oracle.knn_graph(b.x, 8, b.batch, [0, 1, 2])
+    for kw in (dict(global_pooling_schemes=None),
+               dict(global_pooling_schemes=["min", "max", "mean", "sum"], add_global_variables_after_pooling=True),
+               dict(global_pooling_schemes=["mean"], skip_readout=True)):
+        torch.manual_seed(1)
+        ref = oracle.DynEdgeOracle(7, dynedge_layer_sizes=[(128, 256)], **kw)
+        m = g.DynEdge(7, dynedge_layer_sizes=[(128, 256)], **kw)
+        m.load_state_dict(ref.state_dict())
+        m.to(DEV).set_backend(dtype="fp32")
+        y = m(b.to(DEV))
+        b.to("cpu")
+        yo = ref(b.x, ei, b.batch, b.n_pulses)
+        assert y.shape == yo.shape
+        assert rel_err(y, yo.detach()) < 1e-4, kw
+
+
+def test_unsupported_configuration_fails_loudly():
+    import graphnet_amd as g
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    b = synthetic_icecube86_batch(2, seed=1)
+    m = g.DynEdge(7, activation_layer="gelu").to(DEV)
+    with pytest.raises(NotImplementedError):
+        m(b.to(DEV))
+    with pytest.raises(RuntimeError):
+        g.DynEdge(7)(synthetic_icecube86_batch(2, seed=1))       # CPU tensors: no fallback

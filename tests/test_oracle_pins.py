@@ -1,0 +1,93 @@
+"""CPU: pin the oracle against every known answer the reference's own tests hold for this path
+ and against the committed golden fixtures."""
+import numpy as np
+import torch
+
+
+def test_minkowski_distance_known_answers(oracle, golden):
+    ka = golden["reference_known_answers"]        # tests/models/test_minkowski.py:12-101
+    v1, v2 = ka["minkowski_vec1"], ka["minkowski_vec2"]
+    assert np.allclose(oracle.minkowski_distance_mat(v1, v1, 1.0), ka["minkowski_expected11"])
+    assert np.allclose(oracle.minkowski_distance_mat(v1, v2, 1.0), ka["minkowski_expected12"])
+    assert np.allclose(oracle.minkowski_distance_mat(v2, v2, 1.0), ka["minkowski_expected22"])
+    _, dist_c = oracle.minkowski_knn(torch.from_numpy(v1), 2, 1.0)
+    assert np.allclose(dist_c, ka["minkowski_expected11"])
+
+
+def test_minkowski_knn_known_edges(oracle, golden):
+    ka = golden["reference_known_answers"]        # tests/models/test_minkowski.py:104-160
+    ei, _ = oracle.minkowski_knn(torch.from_numpy(ka["minkowski_vec1"]), 2, 1.0)
+    exp = ka["minkowski_knn_k2_edge_index"]
+    assert np.array_equal(ei[1], exp[1])
+    for c in range(4):                            # order inside a centre may permute (as the test allows)
+        assert sorted(ei[0, 2 * c: 2 * c + 2]) == sorted(exp[0, 2 * c: 2 * c + 2])
+
+
+def test_logcosh_known_answers(oracle, golden):
+    x = torch.from_numpy(golden["reference_known_answers"]["logcosh_x"]).unsqueeze(1)
+    y = 0.0 * x
+    losses = oracle.log_cosh_elements(x, y)       # tests/training/test_loss_functions.py:40-63
+    ref = torch.log(torch.cosh(x - y))
+    assert torch.all(torch.isfinite(losses))
+    ok = torch.isfinite(ref)
+    assert torch.allclose(ref[ok], losses[ok])
+
+
+def test_c_knn_matches_python_restatement(oracle):
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(40, 3)).astype(np.float32)
+    x[5:9] = x[4]                                 # duplicates -> ties
+    x[20:32] = x[19]                              # > k duplicates -> degree k+1 in compat mode
+    ptr = [0, 3, 17, 40]
+    for mode in ("compat", "strict"):
+        for k in (2, 8):
+            nbr, deg = oracle.knn_table(torch.from_numpy(x), k, torch.tensor(ptr), None, mode)
+            ei = oracle.table_to_edge_index(nbr).numpy()
+            assert np.array_equal(ei, oracle.knn_graph_py(x, k, ptr, mode)), (mode, k)
+            if mode == "strict":
+                assert int(deg.max()) <= k
+    nbr, deg = oracle.knn_table(torch.from_numpy(x), 8, torch.tensor(ptr), None, "compat")
+    assert int(deg.max()) == 9                    # the k+1 case exists
+    assert int(deg[:3].max()) == 2                # event with 3 nodes -> degree n-1
+
+
+def test_knn_hand_checked_micro_graph(oracle):
+    x = torch.tensor([[0., 0, 0], [1, 0, 0], [3, 0, 0], [7, 0, 0]])
+    ei = oracle.knn_graph(x, 2, None, [0, 1, 2], "compat")
+    assert ei.tolist() == [[1, 2, 0, 2, 1, 0, 2, 1], [0, 0, 1, 1, 2, 2, 3, 3]]
+
+
+def test_oracle_parameter_layout_matches_reference_appendix_b(oracle):
+    m = oracle.StandardModelOracle(7, global_pooling_schemes=["min", "max", "mean", "sum"])
+    sd = m.state_dict()
+    assert sum(v.numel() for v in sd.values()) == 1_382_321
+    assert tuple(sd["backbone._conv_layers.0.nn.0.weight"].shape) == (128, 38)
+    assert tuple(sd["backbone._conv_layers.1.nn.0.weight"].shape) == (336, 512)
+    assert tuple(sd["backbone._post_processing.0.weight"].shape) == (336, 1043)
+    assert tuple(sd["backbone._readout.0.weight"].shape) == (128, 1024)
+
+
+def test_literal_distribute_equals_gather(oracle):
+    torch.manual_seed(0)
+    x = torch.randn(30, 7)
+    batch = torch.repeat_interleave(torch.arange(3), torch.tensor([5, 12, 13]))
+    n = torch.tensor([5, 12, 13], dtype=torch.int32)
+    ei = oracle.knn_graph(x, 4, batch, [0, 1, 2])
+    a = oracle.DynEdgeOracle(7, nb_neighbours=4, global_pooling_schemes=["max"], literal_distribute=True)
+    b = oracle.DynEdgeOracle(7, nb_neighbours=4, global_pooling_schemes=["max"])
+    b.load_state_dict(a.state_dict())
+    assert torch.equal(a(x, ei, batch, n), b(x, ei, batch, n))
+
+
+def test_golden_expected_reproduced(oracle, golden):
+    if "oracle_expected" not in golden:
+        import pytest
+        pytest.skip("oracle_expected.npz not generated")
+    ex, ev = golden["oracle_expected"], golden["reference_events"]
+    for name in ("deepcore", "upgrade", "prometheus"):
+        x = torch.from_numpy(ex[f"{name}_xstd"])
+        for mode in ("compat", "strict"):
+            nbr, _ = oracle.knn_table(x, 8, torch.from_numpy(ev[f"{name}_ptr"]), [0, 1, 2], mode)
+            assert np.array_equal(nbr.numpy(), ex[f"{name}_nbr_{mode}"])
+    # real data has > k pulses on one DOM: the k+1 case is exercised by the reference's own events
+    assert (ex["upgrade_nbr_compat"][:, 8] >= 0).any()
