@@ -50,7 +50,11 @@ def cpu_baseline(events: int, steps: int):
     """The oracle (plain-torch restatement of the PyG formulation) timed on the host cores."""
     from graphnet_amd.synthetic import synthetic_icecube86_batch
     from oracle import dynedge_oracle as orc
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))          # the cores this job may actually use
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("GN_CPU_BASELINE_THREADS", "32"))))
     torch.set_num_threads(cores)
     torch.manual_seed(20241016)
     m = orc.StandardModelOracle(7, global_pooling_schemes=["min", "max", "mean", "sum"], literal_distribute=True)
@@ -175,7 +179,7 @@ def main():
                               "achieved_tflops": 3.0 * flops_fwd * world * args.steps / dt / 1e12,
                               "frac_of_peak": 3.0 * flops_fwd * args.steps / dt / 1e12 / peak},
             "phase_ms_per_step": {k: v[1] / args.steps for k, v in sorted(timers.items(), key=lambda kv: -kv[1][1])},
-            "final_loss": float(loss),
+            "final_loss": float(loss.detach()),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_events, args.cpu_steps)

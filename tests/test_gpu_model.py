@@ -19,6 +19,11 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def norm_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
 def _pair(oracle, F=7, seed=20241016, **kw):
     import graphnet_amd as g
     torch.manual_seed(seed)
@@ -34,7 +39,7 @@ def _pair(oracle, F=7, seed=20241016, **kw):
     return ref, m.to(DEV)
 
 
-@pytest.mark.parametrize("dtype,tol,gtol", [("fp32", 1e-4, 2e-3), ("bf16", 3e-2, 8e-2)])
+@pytest.mark.parametrize("dtype,tol,gtol", [("fp32", 1e-4, 2e-3), ("bf16", 3e-2, 5e-2)])
 def test_full_model_teacher_forced(oracle, dtype, tol, gtol):
     from graphnet_amd.synthetic import synthetic_icecube86_batch
     b = synthetic_icecube86_batch(16, seed=77)
@@ -69,7 +74,9 @@ def test_full_model_teacher_forced(oracle, dtype, tol, gtol):
     go = dict(ref.named_parameters())
     for k, p in m.named_parameters():
         assert p.grad is not None, k
-        assert rel_err(p.grad, go[k].grad) < gtol, f"{dtype}: grad {k}"
+        # bf16: gate on the Frobenius-norm error (single relu gates may flip); fp32: max-abs
+        err = rel_err(p.grad, go[k].grad) if dtype == "fp32" else norm_err(p.grad, go[k].grad)
+        assert err < gtol, f"{dtype}: grad {k}: {err}"
     # (3) free-running oracle: how many neighbour rows agree (reported, loose gate)
     if dtype == "fp32":
         _, tr_free = ref.backbone(bc.x, forced[0], bc.batch, bc.n_pulses, return_trace=True)
