@@ -504,15 +504,29 @@ long long edge_dw2_splits(long long rows) {
         default: { constexpr int S = 32; CALL; } break; \
     }
 
+hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
+                              float* out, long long ldo, unsigned int* maskbits, int num_cus, hipStream_t st);
+
+int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 template <typename T>
 static hipError_t edge_fwd_t(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
-                             float* out, long long ldo, unsigned int* maskbits, hipStream_t st) {
+                             float* out, long long ldo, unsigned int* maskbits, bool main_rows, hipStream_t st) {
     if (g.N == 0) return hipSuccess;
     const int S_ = edge_slots(g.K);
     const int ny = cdiv__(H2, EBN);
     GN_DISPATCH_S(S_, {
-        hipLaunchKernelGGL((edge_fwd_kernel<T, S, false>), dim3(cdiv__((long long)g.N * S, EBM), ny), dim3(256), 0, st,
-                           g, (const T*)PQ, H1p, (const T*)W2p, b2, H2, out, ldo, maskbits);
+        if (main_rows)
+            hipLaunchKernelGGL((edge_fwd_kernel<T, S, false>), dim3(cdiv__((long long)g.N * S, EBM), ny), dim3(256), 0, st,
+                               g, (const T*)PQ, H1p, (const T*)W2p, b2, H2, out, ldo, maskbits);
         if (g.ovf_cnt)
             hipLaunchKernelGGL((edge_fwd_kernel<T, S, true>), dim3(cdiv__(g.N, EBM), ny), dim3(256), 0, st,
                                g, (const T*)PQ, H1p, (const T*)W2p, b2, H2, out, ldo, maskbits);
@@ -522,8 +536,11 @@ static hipError_t edge_fwd_t(const EdgeGraph& g, const void* PQ, int H1p, const 
 hipError_t launch_edge_fwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2,
                            int H2, float* out, long long ldo, unsigned int* maskbits, hipStream_t st) {
     if (H1p % BK || g.K > 32) return hipErrorInvalidValue;
-    return mode == 0 ? edge_fwd_t<float>(g, PQ, H1p, W2p, b2, H2, out, ldo, maskbits, st)
-                     : edge_fwd_t<__bf16>(g, PQ, H1p, W2p, b2, H2, out, ldo, maskbits, st);
+    if (mode == 0) return edge_fwd_t<float>(g, PQ, H1p, W2p, b2, H2, out, ldo, maskbits, true, st);
+    // bf16: persistent weights-stationary kernel for the table rows when the shape allows it
+    hipError_t e = launch_edge_fwd_v2(g, PQ, H1p, W2p, b2, H2, out, ldo, maskbits, device_cus(), st);
+    if (e != hipSuccess && e != hipErrorNotSupported) return e;
+    return edge_fwd_t<__bf16>(g, PQ, H1p, W2p, b2, H2, out, ldo, maskbits, e == hipErrorNotSupported, st);
 }
 
 template <typename T>
