@@ -128,32 +128,38 @@ int gn_reduce_slabs(const float* slab, int32_t nslab, int64_t count, float* out,
     return fail(gn::launch_reduce_slabs(slab, nslab, count, out, accum, S(stream)), "gn_reduce_slabs");
 }
 
+int64_t gn_edgeconv_saved_bytes(int32_t N, int32_t K, int32_t H1p, int32_t H2) {
+    return gn::saved_layout(N, gn::edge_slots(K), H1p, H2).total;
+}
 int gn_edgeconv_fwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
                     const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, const void* W2p,
-                    const float* b2, int32_t H2, float* out, int64_t ldo, uint32_t* maskbits, void* stream) {
+                    const float* b2, int32_t H2, float* out, int64_t ldo, void* saved, void* stream) {
     if (K < 1 || K > 32 || H1p % 32 || H2 < 1) return bad("gn_edgeconv_fwd", "need 1<=K<=32, H1p%32==0");
-    if ((reinterpret_cast<uintptr_t>(PQ) & 15) || (reinterpret_cast<uintptr_t>(W2p) & 15)) return bad("gn_edgeconv_fwd", "alignment");
+    if ((reinterpret_cast<uintptr_t>(PQ) & 15) || (reinterpret_cast<uintptr_t>(W2p) & 15) ||
+        (reinterpret_cast<uintptr_t>(saved) & 15)) return bad("gn_edgeconv_fwd", "alignment");
     return fail(gn::launch_edge_fwd(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, W2p, b2, H2, out,
-                                    ldo, maskbits, S(stream)), "gn_edgeconv_fwd");
+                                    ldo, saved, S(stream)), "gn_edgeconv_fwd");
+}
+int32_t gn_edgeconv_dw2_slabs(int32_t mode, int32_t N, int32_t K, int32_t H1p, int32_t H2) {
+    return gn::edge_dw2_slabs(mode, N, K, H1p, H2);
+}
+int gn_edgeconv_dw2(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
+                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H1, int32_t H2,
+                    const float* gout, int64_t ldg, void* saved, float* slab, float* db2_part, void* stream) {
+    if (K < 1 || K > 32 || H1p % 32 || H1 > H1p || (ldg & 3) || (H2 & 3) || N < 1 ||
+        (reinterpret_cast<uintptr_t>(gout) & 15))
+        return bad("gn_edgeconv_dw2", "bad shapes");
+    return fail(gn::launch_edge_dw2(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, H1, H2, gout, ldg,
+                                    saved, slab, db2_part, S(stream)), "gn_edgeconv_dw2");
 }
 int gn_edgeconv_bwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
                     const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H2,
-                    const float* gout, int64_t ldg, const uint32_t* maskbits, const void* W2Tp, int32_t H2p, void* dpre,
+                    const float* gout, int64_t ldg, const void* saved, const void* W2Tp, int32_t H2p, void* dpre,
                     float* dP, int64_t ldp, void* stream) {
     if (K < 1 || K > 32 || H1p % 32 || H2p % 32 || H2p < H2 || (ldg & 3) || (reinterpret_cast<uintptr_t>(gout) & 15))
         return bad("gn_edgeconv_bwd", "need 1<=K<=32, H1p%32==0, H2p%32==0, gout 16-byte aligned with pitch%4==0");
     return fail(gn::launch_edge_bwd(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, H2, gout, ldg,
-                                    maskbits, W2Tp, H2p, dpre, dP, ldp, S(stream)), "gn_edgeconv_bwd");
-}
-int32_t gn_edgeconv_dw2_splits(int64_t rows) { return (int32_t)gn::edge_dw2_splits(rows); }
-int gn_edgeconv_dw2(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
-                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H1, int32_t H2,
-                    const float* gout, int64_t ldg, const uint32_t* maskbits, float* slab, float* db2_part,
-                    int32_t splits, void* stream) {
-    if (K < 1 || K > 32 || H1p % 32 || H1 > H1p || (ldg & 3) || (H2 & 3) || splits < 1 || N < 1)
-        return bad("gn_edgeconv_dw2", "bad shapes");
-    return fail(gn::launch_edge_dw2(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, H1, H2, gout, ldg,
-                                    maskbits, slab, db2_part, splits, S(stream)), "gn_edgeconv_dw2");
+                                    saved, W2Tp, H2p, dpre, dP, ldp, S(stream)), "gn_edgeconv_bwd");
 }
 int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int32_t* rev_ptr, const int32_t* rev_rows,
                           int32_t N, float* dQ, int64_t ldq, void* stream) {

@@ -22,6 +22,7 @@
 // per centre (8/16/32 >= K); the rare (K+1)-th neighbour of the k+1-then-mask semantics is an
 // "overflow" row t (centre ovf_centre[t], source ovf_src[t]) processed by the OVF variants.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace gn {
 
@@ -319,7 +320,7 @@ template <typename T, int S>
 __global__ __launch_bounds__(256) void edge_dw2_kernel(
     EdgeGraph g, const T* __restrict__ PQ, int H1p, int H1, int H2,
     const float* __restrict__ gout, long long ldg, const unsigned int* __restrict__ maskbits,
-    long long rows_per_split, float* __restrict__ slab, float* __restrict__ db2_part, int n2_tiles)
+    long long row_begin, long long rows_per_split, float* __restrict__ slab, float* __restrict__ db2_part, int n2_tiles)
 {
     constexpr int ROWB = TileCfg<T>::ROWB;
     constexpr int BT = 128;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void edge_dw2_kernel(
     const long long ldpq = 2LL * H1p;
     const long long main_rows = (long long)g.N * S;
     const long long total_rows = main_rows + (g.ovf_cnt ? *g.ovf_cnt : 0);
-    const long long rbeg = split * rows_per_split;
+    const long long rbeg = row_begin + split * rows_per_split;
     const long long rend = min(total_rows, rbeg + rows_per_split);
 
     f32x16 acc[2][2];
@@ -505,7 +506,16 @@ long long edge_dw2_splits(long long rows) {
     }
 
 hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
-                              float* out, long long ldo, unsigned int* maskbits, int num_cus, hipStream_t st);
+                              float* out, long long ldo, unsigned char* maskB, int num_cus, hipStream_t st);
+hipError_t launch_edge_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
+                              long long ldg, const unsigned char* maskB, unsigned char* hbits, float* slab,
+                              float* db2_part, int num_cus, hipStream_t st);
+hipError_t launch_edge_bwd_v2(const EdgeGraph& g, int H1p, int H2, const float* gout, long long ldg,
+                              const unsigned char* maskB, const unsigned char* hbits, const void* W2Tp, int H2p,
+                              void* dpre, float* dP, long long ldp, int num_cus, hipStream_t st);
+bool edge_v2_shape_ok(int K, int H1p, int H2);
+int edge_dw2_v2_parts(int N, int H1p, int num_cus);
+constexpr int DW2_OVF_SPLITS = 8;
 
 int device_cus() {
     static int cus = 0;
@@ -533,26 +543,41 @@ static hipError_t edge_fwd_t(const EdgeGraph& g, const void* PQ, int H1p, const 
     });
     return hipGetLastError();
 }
+static bool v2_enabled() {                       // GN_DISABLE_V2=1 forces the generic kernels (A/B tests)
+    const char* e = getenv("GN_DISABLE_V2");
+    return !(e && e[0] == '1');
+}
+static bool use_v2(int mode, const EdgeGraph& g, int H1p, int H2) {
+    return mode == 1 && v2_enabled() && edge_v2_shape_ok(g.K, H1p, H2);
+}
+
 hipError_t launch_edge_fwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2,
-                           int H2, float* out, long long ldo, unsigned int* maskbits, hipStream_t st) {
+                           int H2, float* out, long long ldo, void* saved, hipStream_t st) {
     if (H1p % BK || g.K > 32) return hipErrorInvalidValue;
-    if (mode == 0) return edge_fwd_t<float>(g, PQ, H1p, W2p, b2, H2, out, ldo, maskbits, true, st);
+    const SavedLayout L = saved_layout(g.N, edge_slots(g.K), H1p, H2);
+    unsigned char* sb = reinterpret_cast<unsigned char*>(saved);
+    unsigned int* words = reinterpret_cast<unsigned int*>(sb + L.off_words);
+    if (mode == 0) return edge_fwd_t<float>(g, PQ, H1p, W2p, b2, H2, out, ldo, words, true, st);
     // bf16: persistent weights-stationary kernel for the table rows when the shape allows it
-    hipError_t e = launch_edge_fwd_v2(g, PQ, H1p, W2p, b2, H2, out, ldo, maskbits, device_cus(), st);
-    if (e != hipSuccess && e != hipErrorNotSupported) return e;
-    return edge_fwd_t<__bf16>(g, PQ, H1p, W2p, b2, H2, out, ldo, maskbits, e == hipErrorNotSupported, st);
+    const bool v2 = use_v2(mode, g, H1p, H2);
+    if (v2) {
+        hipError_t e = launch_edge_fwd_v2(g, PQ, H1p, W2p, b2, H2, out, ldo, sb + L.off_maskB, device_cus(), st);
+        if (e != hipSuccess) return e;
+    }
+    return edge_fwd_t<__bf16>(g, PQ, H1p, W2p, b2, H2, out, ldo, words, !v2, st);
 }
 
 template <typename T>
 static hipError_t edge_bwd_t(const EdgeGraph& g, const void* PQ, int H1p, int H2, const float* gout, long long ldg,
                              const unsigned int* maskbits, const void* W2Tp, int H2p, void* dpre, float* dP,
-                             long long ldp, hipStream_t st) {
+                             long long ldp, bool main_rows, hipStream_t st) {
     if (g.N == 0) return hipSuccess;
     const int S_ = edge_slots(g.K);
     const int ny = cdiv__(H1p, EBN);
     GN_DISPATCH_S(S_, {
-        hipLaunchKernelGGL((edge_bwd_kernel<T, S, false>), dim3(cdiv__((long long)g.N * S, EBM), ny), dim3(256), 0, st,
-                           g, (const T*)PQ, H1p, H2, gout, ldg, maskbits, (const T*)W2Tp, H2p, (T*)dpre, dP, ldp);
+        if (main_rows)
+            hipLaunchKernelGGL((edge_bwd_kernel<T, S, false>), dim3(cdiv__((long long)g.N * S, EBM), ny), dim3(256), 0, st,
+                               g, (const T*)PQ, H1p, H2, gout, ldg, maskbits, (const T*)W2Tp, H2p, (T*)dpre, dP, ldp);
         if (g.ovf_cnt)
             hipLaunchKernelGGL((edge_bwd_kernel<T, S, true>), dim3(cdiv__(g.N, EBM), ny), dim3(256), 0, st,
                                g, (const T*)PQ, H1p, H2, gout, ldg, maskbits, (const T*)W2Tp, H2p, (T*)dpre, dP, ldp);
@@ -560,36 +585,65 @@ static hipError_t edge_bwd_t(const EdgeGraph& g, const void* PQ, int H1p, int H2
     return hipGetLastError();
 }
 hipError_t launch_edge_bwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H2, const float* gout,
-                           long long ldg, const unsigned int* maskbits, const void* W2Tp, int H2p, void* dpre,
+                           long long ldg, const void* saved, const void* W2Tp, int H2p, void* dpre,
                            float* dP, long long ldp, hipStream_t st) {
     if (H1p % BK || H2p % BK || g.K > 32 || (ldg & 3)) return hipErrorInvalidValue;
-    return mode == 0 ? edge_bwd_t<float>(g, PQ, H1p, H2, gout, ldg, maskbits, W2Tp, H2p, dpre, dP, ldp, st)
-                     : edge_bwd_t<__bf16>(g, PQ, H1p, H2, gout, ldg, maskbits, W2Tp, H2p, dpre, dP, ldp, st);
+    const SavedLayout L = saved_layout(g.N, edge_slots(g.K), H1p, H2);
+    const unsigned char* sb = reinterpret_cast<const unsigned char*>(saved);
+    const unsigned int* words = reinterpret_cast<const unsigned int*>(sb + L.off_words);
+    if (mode == 0) return edge_bwd_t<float>(g, PQ, H1p, H2, gout, ldg, words, W2Tp, H2p, dpre, dP, ldp, true, st);
+    const bool v2 = use_v2(mode, g, H1p, H2);
+    if (v2) {      // needs hbits: launch_edge_dw2 of this layer must have run before
+        hipError_t e = launch_edge_bwd_v2(g, H1p, H2, gout, ldg, sb + L.off_maskB, sb + L.off_hbits, W2Tp, H2p, dpre, dP,
+                                          ldp, device_cus(), st);
+        if (e != hipSuccess) return e;
+    }
+    return edge_bwd_t<__bf16>(g, PQ, H1p, H2, gout, ldg, words, W2Tp, H2p, dpre, dP, ldp, !v2, st);
 }
 
-// slab >= splits*H2*H1 floats, db2_part >= splits*H2 floats; reductions are the caller's
-// (launch_reduce_slabs in gemm.hip) so that they can be fused with other slab reductions.
+// Partial results: slab[nslab][H2][H1], db2_part[nslab][H2] with nslab = edge_dw2_slabs(); the caller
+// reduces them in fixed order (launch_reduce_slabs in gemm.hip).
+int edge_dw2_slabs(int mode, int N, int K, int H1p, int H2) {
+    const int S_ = edge_slots(K);
+    if (mode == 1 && v2_enabled() && edge_v2_shape_ok(K, H1p, H2)) return edge_dw2_v2_parts(N, H1p, device_cus()) + DW2_OVF_SPLITS;
+    return (int)edge_dw2_splits((long long)N * S_ + N);
+}
+
 template <typename T>
 static hipError_t edge_dw2_t(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
-                             long long ldg, const unsigned int* maskbits, float* slab, float* db2_part, int splits,
-                             hipStream_t st) {
+                             long long ldg, const unsigned int* maskbits, long long row_begin, long long rows,
+                             float* slab, float* db2_part, int splits, hipStream_t st) {
     const int S_ = edge_slots(g.K);
-    const long long rows = (long long)g.N * S_ + g.N;         // upper bound incl. overflow rows
     long long rps = (rows + splits - 1) / splits;
     rps = (rps + BK - 1) / BK * BK;
     const int n2t = cdiv__(H2, 128), kt = cdiv__(H1, 128);
     GN_DISPATCH_S(S_, {
         hipLaunchKernelGGL((edge_dw2_kernel<T, S>), dim3(n2t * kt, splits), dim3(256), 0, st,
-                           g, (const T*)PQ, H1p, H1, H2, gout, ldg, maskbits, rps, slab, db2_part, n2t);
+                           g, (const T*)PQ, H1p, H1, H2, gout, ldg, maskbits, row_begin, rps, slab, db2_part, n2t);
     });
     return hipGetLastError();
 }
 hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
-                           long long ldg, const unsigned int* maskbits, float* slab, float* db2_part, int splits,
-                           hipStream_t st) {
+                           long long ldg, void* saved, float* slab, float* db2_part, hipStream_t st) {
     if (g.N == 0) return hipErrorInvalidValue;
-    return mode == 0 ? edge_dw2_t<float>(g, PQ, H1p, H1, H2, gout, ldg, maskbits, slab, db2_part, splits, st)
-                     : edge_dw2_t<__bf16>(g, PQ, H1p, H1, H2, gout, ldg, maskbits, slab, db2_part, splits, st);
+    const int S_ = edge_slots(g.K);
+    const SavedLayout L = saved_layout(g.N, S_, H1p, H2);
+    unsigned char* sb = reinterpret_cast<unsigned char*>(saved);
+    const unsigned int* words = reinterpret_cast<const unsigned int*>(sb + L.off_words);
+    const long long main_rows = (long long)g.N * S_;
+    if (mode == 0)
+        return edge_dw2_t<float>(g, PQ, H1p, H1, H2, gout, ldg, words, 0, main_rows + g.N, slab, db2_part,
+                                 edge_dw2_slabs(mode, g.N, g.K, H1p, H2), st);
+    if (!use_v2(mode, g, H1p, H2))
+        return edge_dw2_t<__bf16>(g, PQ, H1p, H1, H2, gout, ldg, words, 0, main_rows + g.N, slab, db2_part,
+                                  edge_dw2_slabs(mode, g.N, g.K, H1p, H2), st);
+    // persistent kernel for the table rows (also writes hbits), generic kernel for the overflow rows
+    const int parts = edge_dw2_v2_parts(g.N, H1p, device_cus());
+    hipError_t e = launch_edge_dw2_v2(g, PQ, H1p, H1, H2, gout, ldg, sb + L.off_maskB, sb + L.off_hbits, slab, db2_part,
+                                      device_cus(), st);
+    if (e != hipSuccess) return e;
+    return edge_dw2_t<__bf16>(g, PQ, H1p, H1, H2, gout, ldg, words, main_rows, g.N,
+                              slab + (long long)parts * H2 * H1, db2_part + (long long)parts * H2, DW2_OVF_SPLITS, st);
 }
 
 hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows, int N,

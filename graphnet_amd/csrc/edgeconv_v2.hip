@@ -1,69 +1,127 @@
-// graphnet_amd/csrc/edgeconv_v2.hip — persistent, weights-stationary fused EdgeConv kernels (bf16).
+// graphnet_amd/csrc/edgeconv_v2.hip — persistent, operand-stationary fused EdgeConv kernels (bf16).
 //
 // MI355X-specific structure (512-entry unified VGPR file, 160 KB LDS, 256 CUs):
-//   * one 512-thread workgroup (8 waves, 2 per SIMD) per CU, persistent over 64-row edge tiles;
-//   * each wave OWNS 32 output columns and keeps its whole W2 slice (K x 32) in registers as MFMA
-//     B fragments for the life of the kernel -> W2 is read from HBM/L2 once per CU, no LDS
-//     traffic and no per-tile staging for the weight operand;
-//   * the A operand (h = relu(P[i]+Q[j]), gathered per edge) is built cooperatively into a
-//     double-buffered LDS tile [64 rows][K] (16-byte row pad -> conflict-free ds_read_b128);
-//     the gather for tile t+1 is in flight while the MFMAs of tile t run (issue-early /
-//     write-late), one barrier per tile;
-//   * epilogue: +b2, relu, relu bits (ballot), segmented slot sum in registers + one
-//     cross-half shuffle, coalesced 128-byte row stores.
+//   * one 512-thread workgroup (8 waves, 2 per SIMD) per CU, persistent over a CONTIGUOUS range of
+//     64-row edge tiles (8 centres x 8 slots): an event's tiles stay on one CU, so the Q rows it
+//     gathers (each reused by ~K centres) are L1/L2 hits;
+//   * the small operand of each contraction never moves: edge_fwd_v2 keeps its W2 slice (K x 32
+//     per wave) in registers as MFMA B fragments, edge_bwd_v2 its W2^T slices, edge_dw2_v2 keeps
+//     the whole dW2 accumulator (256 x H1p fp32 = 176 VGPRs per lane) in registers;
+//   * the gathered operand (h = relu(P[i]+Q[j]) or dm = g_out[i] (.) relu-bits) is built
+//     cooperatively into double-buffered LDS tiles while the MFMAs of the previous tile run
+//     (issue-early / write-late, branch-free, one barrier per tile);
+//   * dW2 contracts over edge rows: its h^T fragments come from the row-major LDS tile through
+//     ds_read_b64_tr_b16 (hardware transpose), its dm^T fragments are built in registers from one
+//     g_out value + one "slot byte" per lane and k-step (the 8 rows of a k-step half are the 8
+//     slots of ONE centre).
 //
-// Shapes: K = H1p in {128, 352} (KSTEPS = K/16 in {8, 22}), H2 <= 256 and H2 % 32 == 0, S = 8.
-// Anything else (and the rare overflow rows, and f32 mode) runs the generic kernels of
-// edgeconv.hip.
+// Saved-for-backward formats (region offsets: saved_layout() in common.hpp):
+//   maskB[centre][H2]  uint8, bit s = second-relu active for slot s     (written by edge_fwd_v2)
+//   hbits[row][H1p/8]  uint8, bit c%8 of byte c/8 = h[row][c] > 0        (written by edge_dw2_v2)
+//
+// Envelope: bf16, K <= 8 (S = 8 slots), H1p in {128, 352}, H2 % 32 == 0 and <= 256 (bwd: == 256).
+// Anything else, the overflow rows, and f32 mode run the generic kernels of edgeconv.hip.
 #include "common.hpp"
 
 namespace gn {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// relu(p + q) on 8 packed bf16: unpack with shift/and, f32 adds, one v_cvt_pk_bf16_f32 per pair and
-// the relu as a packed signed-16-bit max with 0 (bf16 is sign-magnitude: negative <=> int16 < 0).
-// Rows without a neighbour need no zeroing: GEMM rows are independent and the epilogue masks them.
+constexpr int V2_ROWS = 64;     // edge rows per tile = 8 centres x 8 slots
+constexpr int V2_THREADS = 512;
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));   // one v_cvt_pk_bf16_f32
+}
+
+// relu(p + q) on 8 packed bf16: unpack with shift/and, f32 adds, one cvt_pk per pair, relu as a
+// packed signed-16-bit max with 0 (bf16 is sign-magnitude: negative <=> int16 < 0).
 __device__ __forceinline__ u32x4 relu_sum_bf16x8(u32x4 p, u32x4 q) {
     u32x4 o;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         const float plo = __builtin_bit_cast(float, p[w] << 16), phi = __builtin_bit_cast(float, p[w] & 0xffff0000u);
         const float qlo = __builtin_bit_cast(float, q[w] << 16), qhi = __builtin_bit_cast(float, q[w] & 0xffff0000u);
-        bf16x2 s;
-        s[0] = (__bf16)(plo + qlo);
-        s[1] = (__bf16)(phi + qhi);
+        const unsigned int s = pack_bf16x2(plo + qlo, phi + qhi);
         const s16x2 m = __builtin_elementwise_max(__builtin_bit_cast(s16x2, s), (s16x2){0, 0});
         o[w] = __builtin_bit_cast(unsigned int, m);
     }
     return o;
 }
+// 8 "h > 0" flags of a packed NON-NEGATIVE bf16x8 (bit c = column c of the chunk).  For a half in
+// [0, 0x7fff]: half != 0  <=>  bit 15 of (half + 0x7fff); the low half never carries into the high.
+__device__ __forceinline__ unsigned int nonzero_bits_bf16x8(u32x4 o) {
+    unsigned int t = 0;
+#pragma unroll
+    for (int w = 3; w >= 0; --w) {
+        const unsigned int y = o[w] + 0x7fff7fffu;
+        t = (t << 2) | ((y >> 15) & 0x00010001u);
+    }
+    return (t & 0x55u) | ((t >> 15) & 0xAAu);
+}
 
-constexpr int V2_ROWS = 64;     // edge rows per tile
-constexpr int V2_THREADS = 512;
+// ---- shared gather machinery (8 threads per row, thread handles 16-byte chunks (tid&7)+8i) --------
+// Branch-free: out-of-range rows/chunks are clamped to valid addresses (duplicate chunks write
+// identical bytes).  Row info is fetched in two halves so that its load is issued FIRST in an
+// iteration and consumed LAST (vmcnt is in-order: an early use would drain the whole gather).
+#define GN_V2_INFO_ISSUE(tile_, ic_, raw_, ok_)                                                       \
+    {                                                                                                 \
+        long long row__ = (long long)(tile_) * V2_ROWS + grow;                                        \
+        const bool inr__ = ((tile_) < ntiles) && (row__ < main_rows);                                 \
+        row__ = inr__ ? row__ : 0;                                                                    \
+        const int ii__ = (int)(row__ >> 3), sl__ = (int)(row__ & 7);                                  \
+        const int slc__ = sl__ < kslots ? sl__ : 0;                                                   \
+        (raw_) = g.nbr[(long long)ii__ * kslots + slc__];                                             \
+        (ic_) = ii__;                                                                                 \
+        (ok_) = inr__ && sl__ < kslots;                                                               \
+    }
+#define GN_V2_INFO(tile_, ic_, jc_)                                                                   \
+    {                                                                                                 \
+        int raw__; bool ok__;                                                                         \
+        GN_V2_INFO_ISSUE(tile_, ic_, raw__, ok__);                                                    \
+        (jc_) = ok__ ? raw__ : -1;                                                                    \
+    }
+// gathers chunks cbeg_ + (tid&7) + 8i, i < NI_, clamped to cend_-1, of P[ic] and Q[jc]
+#define GN_V2_GATHER_WIN(ic_, jc_, cbeg_, cend_, NI_)                                                 \
+    {                                                                                                 \
+        const int js__ = (jc_) < 0 ? 0 : (jc_);                                                       \
+        const __bf16* pp__ = PQ + (long long)(ic_) * ldpq;                                            \
+        const __bf16* qq__ = PQ + (long long)js__ * ldpq + K;                                         \
+        _Pragma("unroll") for (int i = 0; i < (NI_); ++i) {                                           \
+            const int c__ = (cbeg_) + gc0 + 8 * i;                                                    \
+            const int cc__ = c__ < (cend_) ? c__ : (cend_) - 1;                                       \
+            preg[i] = *reinterpret_cast<const u32x4*>(pp__ + cc__ * 8);                               \
+            qreg[i] = *reinterpret_cast<const u32x4*>(qq__ + cc__ * 8);                               \
+        }                                                                                             \
+    }
 
+// =============================================================================== forward
 template <int KSTEPS>
 __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
     EdgeGraph g, const __bf16* __restrict__ PQ, const __bf16* __restrict__ W2p, const float* __restrict__ b2,
-    int H2, float* __restrict__ out, long long ldo, unsigned int* __restrict__ maskbits, int ntiles)
+    int H2, float* __restrict__ out, long long ldo, unsigned char* __restrict__ maskB, int ntiles)
 {
     constexpr int S = 8;
     constexpr int K = KSTEPS * 16;                 // = H1p
-    constexpr int ROWB = K * 2 + 16;               // LDS row pitch (bytes)
-    constexpr int CHUNKS = K / 8;                  // 16-byte chunks per row
-    constexpr int CPT = (CHUNKS + 7) / 8;          // chunks per thread (8 threads per row)
+    constexpr int ROWB = K * 2 + 16;               // LDS row pitch: conflict-free ds_read_b128
+    constexpr int CHUNKS = K / 8;
+    constexpr int CPT = (CHUNKS + 7) / 8;
     __shared__ __attribute__((aligned(16))) unsigned char As[2][V2_ROWS * ROWB];
     __shared__ int s_jc[2][V2_ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int H2w = (H2 + 31) >> 5;
     const long long ldpq = 2LL * K;
     const long long main_rows = (long long)g.N * S;
     const bool wave_on = wave * 32 < H2;
+    const int kslots = g.K;
 
-    // ---- stationary W2 slice: B fragments for all k-steps (row n = wave*32 + r of W2p)
     bf16x8 w2[KSTEPS];
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s)
@@ -77,158 +135,522 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
     const int col = wave * 32 + r;
     const float bias = (col < H2) ? b2[col] : 0.0f;
 
-    // ---- gather mapping: 8 threads per row, thread handles chunks (tid&7) + 8*i.
-    // Everything here is branch-free: out-of-range rows/chunks are clamped to valid addresses
-    // (chunk duplicates write identical bytes) and invalid rows are zeroed by a select.
+    // the gather of a tile is split in two chunk windows (registers: 2 x 3 x 16 B in flight)
+    constexpr int CH_A = (CHUNKS / 2 + 7) / 8 * 8 < CHUNKS ? (CHUNKS / 2 + 7) / 8 * 8 : CHUNKS;   // first window
+    constexpr int NI_A = CH_A / 8, NI_B = (CHUNKS - CH_A + 7) / 8;
+    constexpr int NI = NI_A > NI_B ? NI_A : NI_B;
     const int grow = tid >> 3, gc0 = tid & 7;
-    u32x4 preg[CPT], qreg[CPT];
-    const int kslots = g.K;
-
-    // row info is fetched in two halves so that the load is issued FIRST in an iteration and
-    // its result is consumed LAST (vmcnt is in-order: an early use would drain the whole gather)
-#define GN_V2_INFO_ISSUE(tile_, ic_, raw_, ok_)                                                       \
+    u32x4 preg[NI > 0 ? NI : 1], qreg[NI > 0 ? NI : 1];
+#define GN_V2_WRITE_H(buf_, cbeg_, cend_, NI_)                                                        \
     {                                                                                                 \
-        long long row = (long long)(tile_) * V2_ROWS + grow;                                          \
-        const bool inr = ((tile_) < ntiles) && (row < main_rows);                                     \
-        row = inr ? row : 0;                                                                          \
-        const int ii = (int)(row >> 3), sl = (int)(row & 7);                                          \
-        const int slc = sl < kslots ? sl : 0;                                                         \
-        (raw_) = g.nbr[(long long)ii * kslots + slc];                                                 \
-        (ic_) = ii;                                                                                   \
-        (ok_) = inr && sl < kslots;                                                                   \
-    }
-#define GN_V2_INFO(tile_, ic_, jc_)                                                                   \
-    {                                                                                                 \
-        int raw__; bool ok__;                                                                         \
-        GN_V2_INFO_ISSUE(tile_, ic_, raw__, ok__);                                                    \
-        (jc_) = ok__ ? raw__ : -1;                                                                    \
-    }
-#define GN_V2_GATHER(ic_, jc_)                                                                        \
-    {                                                                                                 \
-        const int js = (jc_) < 0 ? 0 : (jc_);                                                         \
-        const __bf16* pp = PQ + (long long)(ic_) * ldpq;                                              \
-        const __bf16* qq = PQ + (long long)js * ldpq + K;                                             \
-        _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                             \
-            const int c = gc0 + 8 * i;                                                                \
-            const int cc = c < CHUNKS ? c : CHUNKS - 1;                                               \
-            preg[i] = *reinterpret_cast<const u32x4*>(pp + cc * 8);                                   \
-            qreg[i] = *reinterpret_cast<const u32x4*>(qq + cc * 8);                                   \
+        _Pragma("unroll") for (int i = 0; i < (NI_); ++i) {                                           \
+            const int c__ = (cbeg_) + gc0 + 8 * i;                                                    \
+            const int cc__ = c__ < (cend_) ? c__ : (cend_) - 1;                                       \
+            *reinterpret_cast<u32x4*>(&As[buf_][grow * ROWB + cc__ * 16]) = relu_sum_bf16x8(preg[i], qreg[i]); \
         }                                                                                             \
     }
-#define GN_V2_WRITE(buf, jc_)                                                                         \
-    {                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                             \
-            const int c = gc0 + 8 * i;                                                                \
-            const int cc = c < CHUNKS ? c : CHUNKS - 1;                                               \
-            *reinterpret_cast<u32x4*>(&As[buf][grow * ROWB + cc * 16]) = relu_sum_bf16x8(preg[i], qreg[i]); \
-        }                                                                                             \
-        if (gc0 == 0) s_jc[buf][grow] = (jc_);                                                        \
-    }
 
-    // contiguous tile range per workgroup: an event's tiles stay on one CU, so the Q rows it
-    // gathers (each reused by ~K centres) are L1/L2 hits instead of 8 XCDs fetching them each
     const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
     int tile = blockIdx.x * per;
     const int tile_end = min(ntiles, tile + per);
-    int ic_n, jc_n;                                  // row info of the NEXT tile (one tile ahead)
-    // prologue: stage the first tile, fetch the row info of the second
+    int ic_n, jc_n;
     {
         int ic, jc;
         GN_V2_INFO(tile, ic, jc);
-        GN_V2_GATHER(ic, jc);
+        GN_V2_GATHER_WIN(ic, jc, 0, CH_A, NI_A);
+        GN_V2_WRITE_H(0, 0, CH_A, NI_A);
+        if (NI_B > 0) {
+            GN_V2_GATHER_WIN(ic, jc, CH_A, CHUNKS, NI_B);
+            GN_V2_WRITE_H(0, CH_A, CHUNKS, NI_B);
+        }
+        if (gc0 == 0) s_jc[0][grow] = jc;
         GN_V2_INFO(tile + 1, ic_n, jc_n);
-        GN_V2_WRITE(0, jc);
     }
     __syncthreads();
 
     int buf = 0;
     for (; tile < tile_end; ++tile, buf ^= 1) {
-        // (a) issue the row-info load of tile t+2, then the gather of tile t+1 (whose row info is
-        //     already in registers); all of it stays in flight under the MFMAs
         int ic_nn, raw_nn;
         bool ok_nn;
         GN_V2_INFO_ISSUE(tile + 2, ic_nn, raw_nn, ok_nn);
-        GN_V2_GATHER(ic_n, jc_n);
+        GN_V2_GATHER_WIN(ic_n, jc_n, 0, CH_A, NI_A);
 
-        // (b) MFMAs of this tile: 2 row blocks x KSTEPS
         f32x16 acc0, acc1;
-        zero_acc(acc0); zero_acc(acc1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { acc0[q] = bias; acc1[q] = bias; }
         if (wave_on) {
             const unsigned char* a0 = &As[buf][r * ROWB + h * 16];
             const unsigned char* a1 = a0 + 32 * ROWB;
-            // fragment reads run two k-steps ahead of the MFMAs that consume them
-            bf16x8 f0 = *reinterpret_cast<const bf16x8*>(a0);
-            bf16x8 f1 = *reinterpret_cast<const bf16x8*>(a1);
-            bf16x8 n0 = *reinterpret_cast<const bf16x8*>(a0 + 32);
-            bf16x8 n1 = *reinterpret_cast<const bf16x8*>(a1 + 32);
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
-                bf16x8 m0 = n0, m1 = n1;
-                if (s + 2 < KSTEPS) {
-                    m0 = *reinterpret_cast<const bf16x8*>(a0 + (s + 2) * 32);
-                    m1 = *reinterpret_cast<const bf16x8*>(a1 + (s + 2) * 32);
-                }
+                const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(a0 + s * 32);
+                const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(a1 + s * 32);
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w2[s], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, w2[s], acc1, 0, 0, 0);
-                f0 = n0; f1 = n1; n0 = m0; n1 = m1;
+                if (s == KSTEPS / 2 - 1 && NI_B > 0) {      // mid-tile: retire window A, issue window B
+                    GN_V2_WRITE_H(buf ^ 1, 0, CH_A, NI_A);
+                    GN_V2_GATHER_WIN(ic_n, jc_n, CH_A, CHUNKS, NI_B);
+                }
             }
-        }
 
-        // (c) epilogue
-        if (wave_on) {
-            const long long row0 = (long long)tile * V2_ROWS;
-            const int rL = (r & 3) + 4 * (r >> 3), hL = (r >> 2) & 1;
+            // ---- epilogue: relu, slot bytes (sign trick, no ballots), slot sums
+            const unsigned long long vbits = __ballot(s_jc[buf][lane] >= 0);     // bit = tile row
+            const bool all_valid = (vbits == ~0ull);                              // wave-uniform
+            const unsigned int vrow0 = (unsigned int)(vbits >> (4 * h));          // row block 0, this half
+            const unsigned int vrow1 = (unsigned int)(vbits >> (32 + 4 * h));     // row block 1
+            const long long c0t = (long long)tile * (V2_ROWS / S);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const f32x16& acc = rb ? acc1 : acc0;
-                float v[16];
-                unsigned int word = 0;
+                float sums[4];
+                unsigned int pack = 0;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int rl = rb * 32 + acc_row(q, h);
-                    v[q] = (s_jc[buf][rl] >= 0) ? fmaxf(acc[q] + bias, 0.0f) : 0.0f;
-                    const unsigned long long bal = __ballot(v[q] > 0.0f);
-                    if (q == rL) word = hL ? (unsigned int)(bal >> 32) : (unsigned int)bal;
+                for (int c = 3; c >= 0; --c) {
+                    float sum = 0.0f;
+                    unsigned int nib = 0;
+#pragma unroll
+                    for (int qq = 3; qq >= 0; --qq) {
+                        const int q = 4 * c + qq;
+                        float x = acc[q];
+                        if (!all_valid) x = (((rb ? vrow1 : vrow0) >> acc_row(q, 0)) & 1u) ? x : -1.0f;
+                        sum += fmaxf(x, 0.0f);
+                        const float y = 0.0f - x;                                 // sign(y) = [x > 0]
+                        nib = __builtin_amdgcn_alignbit(nib, __builtin_bit_cast(unsigned int, y), 31);
+                    }
+                    sums[c] = sum;
+                    pack = (pack << 4) | nib;
                 }
-                if (lane < 32) {
-                    const long long rowg = row0 + rb * 32 + r;
-                    if (rowg < main_rows) maskbits[rowg * H2w + wave] = word;
-                }
-                const long long c0 = (row0 + rb * 32) / S;
+                const unsigned int other = __shfl_xor(pack, 32);
+                const unsigned int lo16 = h ? other : pack, hi16 = h ? pack : other;   // slots 0-3 / 4-7
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    float sum = v[4 * c] + v[4 * c + 1] + v[4 * c + 2] + v[4 * c + 3];
-                    sum += __shfl_xor(sum, 32);
-                    if ((c >> 1) == h && c0 + c < g.N) out[(c0 + c) * ldo + col] = sum;
+                    const float sum = sums[c] + __shfl_xor(sums[c], 32);
+                    const long long centre = c0t + rb * 4 + c;
+                    if ((c >> 1) == h && centre < g.N) {
+                        out[centre * ldo + col] = sum;
+                        maskB[centre * H2 + col] =
+                            (unsigned char)(((lo16 >> (4 * c)) & 0xFu) | (((hi16 >> (4 * c)) & 0xFu) << 4));
+                    }
                 }
             }
         }
 
-        // (d) finish staging the next tile into the other buffer
-        GN_V2_WRITE(buf ^ 1, jc_n);
+        if (!wave_on && NI_B > 0) {                         // idle-column waves still stage their share
+            GN_V2_WRITE_H(buf ^ 1, 0, CH_A, NI_A);
+            GN_V2_GATHER_WIN(ic_n, jc_n, CH_A, CHUNKS, NI_B);
+        }
+        if (NI_B > 0) { GN_V2_WRITE_H(buf ^ 1, CH_A, CHUNKS, NI_B); }
+        else { GN_V2_WRITE_H(buf ^ 1, 0, CH_A, NI_A); }
+        if (gc0 == 0) s_jc[buf ^ 1][grow] = jc_n;
         ic_n = ic_nn; jc_n = ok_nn ? raw_nn : -1;
         __syncthreads();
     }
-#undef GN_V2_INFO
-#undef GN_V2_INFO_ISSUE
-#undef GN_V2_GATHER
-#undef GN_V2_WRITE
+#undef GN_V2_WRITE_H
 }
 
-// returns hipErrorNotSupported when the shape is outside the v2 envelope (caller falls back)
+// =============================================================================== dW2 / db2 / hbits
+// LDS pitch for tiles read with ds_read_b64_tr_b16: 4 consecutive rows must hit disjoint 64-byte
+// bank ranges -> pitch == 64 (mod 256).
+__host__ __device__ constexpr int tr_pitch(int row_bytes) {
+    return row_bytes + ((64 - row_bytes % 256) + 256) % 256;
+}
+
+// The k1 (= H1p) range is split over HALVES workgroup populations so that the stationary
+// accumulator (32 x NBH*32 fp32 per wave) fits the 256-VGPR budget of 2 waves/SIMD: workgroup b
+// handles k1 blocks [kb0, kb0+nblk) (kb0 = (b % HALVES) * NBH) of the tile range b / HALVES, gathers
+// only those columns of h, and writes them into slab b / HALVES.
+template <int NB1, int NBH, int HALVES>   // H1p = 32 * NB1
+__global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
+    EdgeGraph g, const __bf16* __restrict__ PQ, int H1, int H2,
+    const float* __restrict__ gout, long long ldg, const unsigned char* __restrict__ maskB,
+    unsigned char* __restrict__ hbits, float* __restrict__ slab, float* __restrict__ db2_part, int ntiles)
+{
+    constexpr int S = 8;
+    constexpr int K = NB1 * 32;
+    constexpr int CHUNKS = K / 8;
+    constexpr int NI = (NBH * 4 + 7) / 8;           // 16-byte chunks per thread (8 threads per row)
+    constexpr int HP = tr_pitch(NBH * 64);
+    __shared__ __attribute__((aligned(16))) unsigned char Hs[2][V2_ROWS * HP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long ldpq = 2LL * K;
+    const long long main_rows = (long long)g.N * S;
+    const bool wave_on = wave * 32 < H2;
+    const int kslots = g.K;
+    const int n2 = wave * 32 + r;                   // dm column owned by this lane (A rows)
+    const int n2c = n2 < H2 ? n2 : 0;
+    const int half = (int)blockIdx.x % HALVES, part = (int)blockIdx.x / HALVES;
+    const int nparts = ((int)gridDim.x + HALVES - 1) / HALVES;
+    const int kb0 = half * NBH;
+    const int nblk = (NB1 - kb0) < NBH ? (NB1 - kb0) : NBH;       // k1 blocks of this workgroup
+    const int cbeg = kb0 * 4, cend = (kb0 + nblk) * 4;             // its chunk window
+
+    f32x16 acc[NBH];
+#pragma unroll
+    for (int nb = 0; nb < NBH; ++nb) zero_acc(acc[nb]);
+    float bsum = 0.0f;
+
+    const int grow = tid >> 3, gc0 = tid & 7;
+    u32x4 preg[NI], qreg[NI];
+#define GN_V2_WRITE_HT(buf_, tile_)                                                                   \
+    {                                                                                                 \
+        const long long rowg__ = (long long)(tile_) * V2_ROWS + grow;                                 \
+        const bool rok__ = (tile_) < ntiles && rowg__ < main_rows;                                    \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
+            const int c__ = cbeg + gc0 + 8 * i;                                                       \
+            const int cc__ = c__ < cend ? c__ : cend - 1;                                             \
+            const u32x4 hv__ = relu_sum_bf16x8(preg[i], qreg[i]);                                     \
+            *reinterpret_cast<u32x4*>(&Hs[buf_][grow * HP + (cc__ - cbeg) * 16]) = hv__;              \
+            if (rok__) hbits[rowg__ * CHUNKS + cc__] = (unsigned char)nonzero_bits_bf16x8(hv__);      \
+        }                                                                                             \
+    }
+    // A-side operands of one tile: per k-step s the lane needs g_out and the slot byte of centre
+    // (8*tile + 2s + h) at column n2; the four slot bytes are packed into one register
+#define GN_V2_LOAD_A(tile_, gv_, mv_)                                                                 \
+    {                                                                                                 \
+        (mv_) = 0u;                                                                                   \
+        _Pragma("unroll") for (int s = 3; s >= 0; --s) {                                              \
+            const long long c__ = (long long)(tile_) * 8 + 2 * s + h;                                 \
+            const bool ok__ = (tile_) < ntiles && c__ < g.N && n2 < H2;                               \
+            const long long cs__ = ok__ ? c__ : 0;                                                    \
+            const float gl__ = gout[cs__ * ldg + n2c];                                                \
+            const unsigned int ml__ = maskB[cs__ * H2 + n2c];                                         \
+            gv_[s] = ok__ ? gl__ : 0.0f;                                                              \
+            (mv_) = ((mv_) << 8) | (ok__ ? ml__ : 0u);                                                \
+        }                                                                                             \
+    }
+
+    const int per = (ntiles + nparts - 1) / nparts;
+    int tile = part * per;
+    const int tile_end = min(ntiles, tile + per);
+    int ic_n, jc_n;
+    float ga[4], gb[4];
+    unsigned int ma, mb;
+    {
+        int ic, jc;
+        GN_V2_INFO(tile, ic, jc);
+        GN_V2_GATHER_WIN(ic, jc, cbeg, cend, NI);
+        GN_V2_INFO(tile + 1, ic_n, jc_n);
+        GN_V2_LOAD_A(tile, ga, ma);
+        GN_V2_WRITE_HT(0, tile);
+    }
+    __syncthreads();
+
+    // per-lane base of the transposed reads (k-step 0, k1 block 0, first 4-row half)
+    const int g4 = lane >> 4, li = lane & 15;
+    const int tr_base = (8 * (g4 >> 1) + (li >> 2)) * HP + (16 * (g4 & 1) + 4 * (li & 3)) * 2;
+
+    int buf = 0;
+    for (; tile < tile_end; ++tile, buf ^= 1) {
+        int ic_nn, raw_nn;
+        bool ok_nn;
+        GN_V2_INFO_ISSUE(tile + 2, ic_nn, raw_nn, ok_nn);
+        GN_V2_LOAD_A(tile + 1, gb, mb);
+        GN_V2_GATHER_WIN(ic_n, jc_n, cbeg, cend, NI);
+
+        if (wave_on) {
+            const unsigned char* hb = &Hs[buf][tr_base];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                // dm^T fragment: 8 k (= the 8 slots of one centre) of column n2
+                const unsigned int gbf = pack_bf16x2(ga[s], ga[s]);
+                const unsigned int m = (ma >> (8 * s)) & 0xffu;
+                bsum += ga[s] * (float)__builtin_popcount(m);
+                u32x4 aw;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int b0 = __builtin_amdgcn_sbfe((int)m, 2 * jj, 1);
+                    const int b1 = __builtin_amdgcn_sbfe((int)m, 2 * jj + 1, 1);
+                    const unsigned int mk = ((unsigned int)b1 & 0xffff0000u) | ((unsigned int)b0 & 0x0000ffffu);
+                    aw[jj] = gbf & mk;
+                }
+                const bf16x8 afrag = __builtin_bit_cast(bf16x8, aw);
+#pragma unroll
+                for (int nb = 0; nb < NBH; ++nb) {
+                    if (nb < nblk) {                                   // workgroup-uniform
+                        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                        const unsigned char* p0 = hb + (16 * s) * HP + nb * 64;
+                        const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+                        const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * HP));
+                        const s16x8 bb = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, bb), acc[nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        GN_V2_WRITE_HT(buf ^ 1, tile + 1);
+        ic_n = ic_nn; jc_n = ok_nn ? raw_nn : -1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ga[s] = gb[s];
+        ma = mb;
+        __syncthreads();
+    }
+#undef GN_V2_WRITE_HT
+#undef GN_V2_LOAD_A
+
+    // ---- write this workgroup's part of slab `part`: dW2[H2][k1 window] and (half 0) db2[H2]
+    if (wave_on) {
+        float* outp = slab + (long long)part * H2 * H1;
+#pragma unroll
+        for (int nb = 0; nb < NBH; ++nb) {
+            const int k1 = (kb0 + nb) * 32 + r;
+            if (nb < nblk && k1 < H1) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = wave * 32 + acc_row(q, h);
+                    if (row < H2) outp[(long long)row * H1 + k1] = acc[nb][q];
+                }
+            }
+        }
+        bsum += __shfl_xor(bsum, 32);
+        if (half == 0 && h == 0 && n2 < H2) db2_part[(long long)part * H2 + n2] = bsum;
+    }
+}
+
+// =============================================================================== backward (dh, dP, dpre)
+// One wave per 32-column block of dh: NB1 = 11 -> an 11-wave (704-thread) workgroup, 3 waves on
+// three SIMDs (VGPR budget 168): W2^T slice 64 + accumulators 32 + staging.  NB1 = 4 -> 8 waves.
+template <int NB1>   // H1p = 32 * NB1, H2 == 256
+__global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
+    EdgeGraph g, const float* __restrict__ gout, long long ldg, const unsigned char* __restrict__ maskB,
+    const unsigned char* __restrict__ hbits, const __bf16* __restrict__ W2Tp,
+    __bf16* __restrict__ dpre, float* __restrict__ dP, long long ldp, int ntiles)
+{
+    constexpr int S = 8;
+    constexpr int NT = (NB1 > 8 ? NB1 : 8) * 64;   // threads
+    constexpr int K = NB1 * 32;                    // output width (H1p)
+    constexpr int K2 = 256, KS2 = K2 / 16;         // contraction (H2)
+    constexpr int DP = K2 * 2 + 16;                // dm tile pitch (b128 reads)
+    constexpr int SP = K * 2 + 16;                 // dpre staging pitch
+    constexpr int CHUNKS = K / 8;
+    constexpr int CPT = (CHUNKS + 7) / 8;
+    constexpr int HBW = (V2_ROWS * NB1 + NT - 1) / NT;   // hbits words per thread
+    __shared__ __attribute__((aligned(16))) unsigned char Ds[2][V2_ROWS * DP];
+    __shared__ __attribute__((aligned(16))) unsigned int Hb[2][V2_ROWS * NB1];
+    __shared__ __attribute__((aligned(16))) unsigned char Stage[V2_ROWS * SP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long main_rows = (long long)g.N * S;
+    const bool wave_on = wave < NB1;
+    const bool builder = wave < 8;                  // waves 0-7 build the dm tile (wave = centre)
+
+    // stationary W2^T slice: row n = 32*wave + r of W2Tp [.., K2]
+    bf16x8 wa[KS2];
+#pragma unroll
+    for (int s = 0; s < KS2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wa[s][e] = (__bf16)0.0f;
+    if (wave_on) {
+        const __bf16* wrow = W2Tp + (long long)(wave * 32 + r) * K2 + h * 8;
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) wa[s] = *reinterpret_cast<const bf16x8*>(wrow + s * 16);
+    }
+
+    // dm build mapping: wave = centre of the tile, lane&31 = 8-column chunk, lane>>5 = slot half
+    const int bcl = wave & 7, bcc = lane & 31, bsh = lane >> 5;
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+    unsigned int mlo = 0, mhi = 0;
+    unsigned int hbw[HBW];
+#define GN_V2_LOAD_DM(tile_)                                                                          \
+    {                                                                                                 \
+        if (builder) {                                                                                \
+            const long long c__ = (long long)(tile_) * 8 + bcl;                                       \
+            const bool ok__ = (tile_) < ntiles && c__ < g.N;                                          \
+            const long long cs__ = ok__ ? c__ : 0;                                                    \
+            const float* gp__ = gout + cs__ * ldg + bcc * 8;                                          \
+            g0 = *reinterpret_cast<const f32x4*>(gp__);                                               \
+            g1 = *reinterpret_cast<const f32x4*>(gp__ + 4);                                           \
+            const unsigned int* mp__ = reinterpret_cast<const unsigned int*>(maskB + cs__ * K2 + bcc * 8); \
+            const unsigned int l__ = mp__[0], u__ = mp__[1];                                          \
+            mlo = ok__ ? l__ : 0u;                                                                    \
+            mhi = ok__ ? u__ : 0u;                                                                    \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < HBW; ++i) {                                             \
+            const int w__ = tid + NT * i;                        /* word index in [64][NB1] */        \
+            const long long rowg__ = (long long)(tile_) * V2_ROWS + w__ / NB1;                        \
+            const bool okw__ = (tile_) < ntiles && w__ < V2_ROWS * NB1 && rowg__ < main_rows;         \
+            const long long idx__ = okw__ ? rowg__ * NB1 + (w__ % NB1) : 0;                           \
+            const unsigned int v__ = reinterpret_cast<const unsigned int*>(hbits)[idx__];             \
+            hbw[i] = okw__ ? v__ : 0u;                                                                \
+        }                                                                                             \
+    }
+#define GN_V2_WRITE_DM(buf_)                                                                          \
+    {                                                                                                 \
+        if (builder) {                                                                                \
+            unsigned int gw__[4];                                                                     \
+            gw__[0] = pack_bf16x2(g0[0], g0[1]); gw__[1] = pack_bf16x2(g0[2], g0[3]);                 \
+            gw__[2] = pack_bf16x2(g1[0], g1[1]); gw__[3] = pack_bf16x2(g1[2], g1[3]);                 \
+            _Pragma("unroll") for (int si = 0; si < 4; ++si) {                                        \
+                const int slot__ = 4 * bsh + si;                                                      \
+                const unsigned int flo__ = (mlo >> slot__) & 0x01010101u;                             \
+                const unsigned int fhi__ = (mhi >> slot__) & 0x01010101u;                             \
+                u32x4 dw__;                                                                           \
+                _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                    \
+                    const unsigned int f__ = jj < 2 ? flo__ : fhi__;                                  \
+                    const unsigned int sel__ = (jj & 1) ? 0x0c030c02u : 0x0c010c00u;                  \
+                    const unsigned int e__ = __builtin_amdgcn_perm(0u, f__, sel__);  /* {b,0,b',0} */ \
+                    const s16x2 mk__ = (s16x2){0, 0} - __builtin_bit_cast(s16x2, e__);                \
+                    dw__[jj] = gw__[jj] & __builtin_bit_cast(unsigned int, mk__);                     \
+                }                                                                                     \
+                *reinterpret_cast<u32x4*>(&Ds[buf_][(8 * bcl + slot__) * DP + bcc * 16]) = dw__;      \
+            }                                                                                         \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < HBW; ++i) {                                             \
+            const int w__ = tid + NT * i;                                                             \
+            if (w__ < V2_ROWS * NB1) Hb[buf_][w__] = hbw[i];                                          \
+        }                                                                                             \
+    }
+
+    const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    int tile = blockIdx.x * per;
+    const int tile_end = min(ntiles, tile + per);
+    GN_V2_LOAD_DM(tile);
+    GN_V2_WRITE_DM(0);
+    __syncthreads();
+
+    const int grow = tid >> 3, gc0 = tid & 7;
+    int buf = 0;
+    for (; tile < tile_end; ++tile, buf ^= 1) {
+        GN_V2_LOAD_DM(tile + 1);
+
+        if (wave_on) {
+            f32x16 a0, a1;                               // row blocks 0 / 1
+            zero_acc(a0); zero_acc(a1);
+            const unsigned char* p0 = &Ds[buf][r * DP + h * 16];
+            const unsigned char* p1 = p0 + 32 * DP;
+            bf16x8 f0 = *reinterpret_cast<const bf16x8*>(p0);
+            bf16x8 f1 = *reinterpret_cast<const bf16x8*>(p1);
+            bf16x8 n0 = *reinterpret_cast<const bf16x8*>(p0 + 32);
+            bf16x8 n1 = *reinterpret_cast<const bf16x8*>(p1 + 32);
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                bf16x8 m0 = n0, m1 = n1;
+                if (s + 2 < KS2) {
+                    m0 = *reinterpret_cast<const bf16x8*>(p0 + (s + 2) * 32);
+                    m1 = *reinterpret_cast<const bf16x8*>(p1 + (s + 2) * 32);
+                }
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, wa[s], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, wa[s], a1, 0, 0, 0);
+                f0 = n0; f1 = n1; n0 = m0; n1 = m1;
+            }
+
+            // ---- epilogue: (.) [h > 0], slot sums -> dP, dpre tile -> LDS staging
+            const long long c0t = (long long)tile * (V2_ROWS / S);
+            const int nb = wave;
+            const int col = nb * 32 + r;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const f32x16& acc = rb ? a1 : a0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int q = 4 * c + qq;
+                        const int rl = rb * 32 + acc_row(q, h);
+                        const unsigned int word = Hb[buf][rl * NB1 + nb];
+                        const int mk = __builtin_amdgcn_sbfe((int)(word >> r), 0, 1);      // 0 / -1
+                        const float av = acc[q];   // NB: never __builtin_bit_cast a vector ELEMENT lvalue (reads element 0)
+                        const float d = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, av) & (unsigned int)mk);
+                        sum += d;
+                        *reinterpret_cast<__bf16*>(&Stage[rl * SP + col * 2]) = (__bf16)d;
+                    }
+                    sum += __shfl_xor(sum, 32);
+                    const long long centre = c0t + rb * 4 + c;
+                    if ((c >> 1) == h && centre < g.N) dP[centre * ldp + col] = sum;
+                }
+            }
+        }
+        __syncthreads();                                  // staging tile complete
+
+        // cooperative, coalesced store of the dpre tile (full 16-byte chunks of each row)
+        if (tid < V2_ROWS * 8) {
+            const long long rowg = (long long)tile * V2_ROWS + grow;
+            if (rowg < main_rows) {
+#pragma unroll
+                for (int i = 0; i < CPT; ++i) {
+                    const int c = gc0 + 8 * i;
+                    const int cc = c < CHUNKS ? c : CHUNKS - 1;
+                    *reinterpret_cast<u32x4*>(dpre + rowg * K + cc * 8) =
+                        *reinterpret_cast<const u32x4*>(&Stage[grow * SP + cc * 16]);
+                }
+            }
+        }
+        GN_V2_WRITE_DM(buf ^ 1);
+        __syncthreads();
+    }
+#undef GN_V2_LOAD_DM
+#undef GN_V2_WRITE_DM
+}
+
+#undef GN_V2_INFO_ISSUE
+#undef GN_V2_INFO
+#undef GN_V2_GATHER_WIN
+
+// =============================================================================== launchers
+// hipErrorNotSupported = shape outside the v2 envelope (caller falls back to the generic kernels)
+static inline int v2_tiles(const EdgeGraph& g) { return (int)(((long long)g.N * 8 + V2_ROWS - 1) / V2_ROWS); }
+bool edge_v2_shape_ok(int K, int H1p, int H2) {
+    return K <= 8 && H2 == 256 && (H1p == 128 || H1p == 352);
+}
+
 hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
-                              float* out, long long ldo, unsigned int* maskbits, int num_cus, hipStream_t st) {
-    if (g.K > 8 || H2 > 256 || (H2 & 31) || (H1p != 128 && H1p != 352)) return hipErrorNotSupported;
+                              float* out, long long ldo, unsigned char* maskB, int num_cus, hipStream_t st) {
+    if (!edge_v2_shape_ok(g.K, H1p, H2)) return hipErrorNotSupported;
     if (g.N == 0) return hipSuccess;
-    const long long rows = (long long)g.N * 8;
-    const int ntiles = (int)((rows + V2_ROWS - 1) / V2_ROWS);
+    const int ntiles = v2_tiles(g);
     const int grid = ntiles < num_cus ? ntiles : num_cus;
     if (H1p == 128)
         hipLaunchKernelGGL((edge_fwd_v2_kernel<8>), dim3(grid), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
-                           (const __bf16*)W2p, b2, H2, out, ldo, maskbits, ntiles);
+                           (const __bf16*)W2p, b2, H2, out, ldo, maskB, ntiles);
     else
         hipLaunchKernelGGL((edge_fwd_v2_kernel<22>), dim3(grid), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
-                           (const __bf16*)W2p, b2, H2, out, ldo, maskbits, ntiles);
+                           (const __bf16*)W2p, b2, H2, out, ldo, maskB, ntiles);
+    return hipGetLastError();
+}
+
+// number of slabs (= tile-range parts) the dW2 kernel writes for N nodes
+int edge_dw2_v2_parts(int N, int H1p, int num_cus) {
+    const long long ntiles = ((long long)N * 8 + V2_ROWS - 1) / V2_ROWS;
+    const int halves = H1p == 352 ? 2 : 1;
+    long long parts = num_cus / halves;
+    if (parts > ntiles) parts = ntiles;
+    return parts > 0 ? (int)parts : 1;
+}
+
+// slab: [parts][H2][H1], db2_part: [parts][H2] with parts = edge_dw2_v2_parts()
+hipError_t launch_edge_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
+                              long long ldg, const unsigned char* maskB, unsigned char* hbits, float* slab,
+                              float* db2_part, int num_cus, hipStream_t st) {
+    if (!edge_v2_shape_ok(g.K, H1p, H2)) return hipErrorNotSupported;
+    if (g.N == 0) return hipSuccess;
+    const int ntiles = v2_tiles(g);
+    const int parts = edge_dw2_v2_parts(g.N, H1p, num_cus);
+    if (H1p == 128)
+        hipLaunchKernelGGL((edge_dw2_v2_kernel<4, 4, 1>), dim3(parts), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
+                           H1, H2, gout, ldg, maskB, hbits, slab, db2_part, ntiles);
+    else
+        hipLaunchKernelGGL((edge_dw2_v2_kernel<11, 6, 2>), dim3(parts * 2), dim3(V2_THREADS), 0, st, g,
+                           (const __bf16*)PQ, H1, H2, gout, ldg, maskB, hbits, slab, db2_part, ntiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_edge_bwd_v2(const EdgeGraph& g, int H1p, int H2, const float* gout, long long ldg,
+                              const unsigned char* maskB, const unsigned char* hbits, const void* W2Tp, int H2p,
+                              void* dpre, float* dP, long long ldp, int num_cus, hipStream_t st) {
+    if (!edge_v2_shape_ok(g.K, H1p, H2) || H2p != 256) return hipErrorNotSupported;
+    if (g.N == 0) return hipSuccess;
+    const int ntiles = v2_tiles(g);
+    const int grid = ntiles < num_cus ? ntiles : num_cus;
+    if (H1p == 128)
+        hipLaunchKernelGGL((edge_bwd_v2_kernel<4>), dim3(grid), dim3(512), 0, st, g, gout, ldg, maskB, hbits,
+                           (const __bf16*)W2Tp, (__bf16*)dpre, dP, ldp, ntiles);
+    else
+        hipLaunchKernelGGL((edge_bwd_v2_kernel<11>), dim3(grid), dim3(704), 0, st, g, gout, ldg, maskB, hbits,
+                           (const __bf16*)W2Tp, (__bf16*)dpre, dP, ldp, ntiles);
     return hipGetLastError();
 }
 

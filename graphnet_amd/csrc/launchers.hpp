@@ -34,13 +34,13 @@ hipError_t launch_reduce_slabs(const float* slab, int nslab, long long count, fl
 int edge_slots(int K);
 long long edge_dw2_splits(long long rows);
 hipError_t launch_edge_fwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2,
-                           int H2, float* out, long long ldo, unsigned int* maskbits, hipStream_t st);
+                           int H2, float* out, long long ldo, void* saved, hipStream_t st);
 hipError_t launch_edge_bwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H2, const float* gout,
-                           long long ldg, const unsigned int* maskbits, const void* W2Tp, int H2p, void* dpre,
+                           long long ldg, const void* saved, const void* W2Tp, int H2p, void* dpre,
                            float* dP, long long ldp, hipStream_t st);
+int edge_dw2_slabs(int mode, int N, int K, int H1p, int H2);
 hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
-                           long long ldg, const unsigned int* maskbits, float* slab, float* db2_part, int splits,
-                           hipStream_t st);
+                           long long ldg, void* saved, float* slab, float* db2_part, hipStream_t st);
 hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows, int N,
                             float* dQ, long long ldq, hipStream_t st);
 // pool.hip

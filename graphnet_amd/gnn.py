@@ -196,9 +196,9 @@ class _DynEdgeFunction(torch.autograd.Function):
             g_out = dXcat[:, seg_off[l + 1]: seg_off[l + 1] + H2]
             dPQ = torch.empty((N, 2 * H1p), dtype=torch.float32, device=dev)
             dpre = torch.empty((max(g.rows, 1), H1p), dtype=dt, device=dev)
+            dW2, db2 = ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, g_out, mask)   # also records h>0 bits
             ops.edgeconv_bwd(mode, g, PQ, H1p, H2, g_out, mask, ops.pack_weight(W2.t(), [H2], dt), dpre,
                              dPQ[:, :H1p])
-            dW2, db2 = ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, g_out, mask)
             ops.edgeconv_dq_gather(mode, g, dpre, H1p, dPQ[:, H1p:])
             dWpq = ops.linear_wgrad(mode, dPQ, 2 * H1p, [(xin, _kw(Fin))])[:, :Fin]
             dWp, dWq = dWpq[:H1], dWpq[H1p:H1p + H1]

@@ -303,7 +303,8 @@ def edgeconv_fwd(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, W2p: Tensor
     N = g.N
     if out is None:
         out = torch.empty((N, H2), dtype=torch.float32, device=PQ.device)
-    mask = torch.empty(max(g.rows, 1) * ((H2 + 31) // 32), dtype=torch.int32, device=PQ.device)
+    nbytes = int(_lib.lib().gn_edgeconv_saved_bytes(N, g.K, H1p, H2))
+    mask = torch.empty(nbytes, dtype=torch.uint8, device=PQ.device)     # opaque saved-for-backward buffer
     with _timed("edgeconv_fwd"):
         _lib.check(_lib.lib().gn_edgeconv_fwd(mode, *g.c_args(), _p(PQ), H1p, _p(W2p), _p(b2), H2, _p(out),
                                               _rows(out, "out"), _p(mask), _st()))
@@ -321,19 +322,20 @@ def edgeconv_bwd(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, H2: int, go
 
 def edgeconv_dw2(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, H1: int, H2: int, gout: Tensor,
                  mask: Tensor) -> Tuple[Tensor, Tensor]:
-    """Returns (dW2 [H2, H1], db2 [H2])."""
+    """Returns (dW2 [H2, H1], db2 [H2]).  Must run before :func:`edgeconv_bwd` of the same layer."""
     L = _lib.lib()
-    splits = int(L.gn_edgeconv_dw2_splits(g.rows))
+    nslab = int(L.gn_edgeconv_dw2_slabs(mode, g.N, g.K, H1p, H2))
     dev = PQ.device
-    slab = torch.empty(splits * H2 * H1, dtype=torch.float32, device=dev)
-    bpart = torch.empty(splits * H2, dtype=torch.float32, device=dev)
+    slab = torch.empty(nslab * H2 * H1, dtype=torch.float32, device=dev)
+    bpart = torch.empty(nslab * H2, dtype=torch.float32, device=dev)
     with _timed("edgeconv_dw2"):
         _lib.check(L.gn_edgeconv_dw2(mode, *g.c_args(), _p(PQ), H1p, H1, H2, _p(gout), _rows(gout, "gout"), _p(mask),
-                                     _p(slab), _p(bpart), splits, _st()))
+                                     _p(slab), _p(bpart), _st()))
     dW2 = torch.empty((H2, H1), dtype=torch.float32, device=dev)
     db2 = torch.empty(H2, dtype=torch.float32, device=dev)
-    _lib.check(L.gn_reduce_slabs(_p(slab), splits, H2 * H1, _p(dW2), 0, _st()))
-    _lib.check(L.gn_reduce_slabs(_p(bpart), splits, H2, _p(db2), 0, _st()))
+    with _timed("reduce_slabs"):
+        _lib.check(L.gn_reduce_slabs(_p(slab), nslab, H2 * H1, _p(dW2), 0, _st()))
+        _lib.check(L.gn_reduce_slabs(_p(bpart), nslab, H2, _p(db2), 0, _st()))
     return dW2, db2
 
 

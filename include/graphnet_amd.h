@@ -99,23 +99,28 @@ int gn_reduce_slabs(const float* slab, int32_t nslab, int64_t count, float* out,
 
 /* ---- fused EdgeConv (torch_geometric.nn.EdgeConv via DynEdgeConv, layers.py:55-60) ---- */
 
-/* out[i, :H2] = sum_slots relu(relu(P[i]+Q[j]) . W2^T + b2); PQ: T[N, 2*H1p]; W2p: T[ceil128(H2)][H1p];
- * maskbits: uint32[(N*S + N) * ceil(H2/32)] (relu bits for backward). */
+/* `saved`: opaque per-layer buffer of gn_edgeconv_saved_bytes() bytes holding the relu bits the
+ * backward needs (layout: graphnet_amd/csrc/common.hpp saved_layout()). */
+int64_t gn_edgeconv_saved_bytes(int32_t N, int32_t K, int32_t H1p, int32_t H2);
+
+/* out[i, :H2] = sum_slots relu(relu(P[i]+Q[j]) . W2^T + b2); PQ: T[N, 2*H1p]; W2p: T[ceil128(H2)][H1p] */
 int gn_edgeconv_fwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
                     const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p,
                     const void* W2p, const float* b2, int32_t H2, float* out, int64_t ldo,
-                    uint32_t* maskbits, void* stream);
+                    void* saved, void* stream);
+/* dW2 / db2 partials: slab[nslab][H2][H1], db2_part[nslab][H2], nslab = gn_edgeconv_dw2_slabs();
+ * reduce with gn_reduce_slabs.  Must run BEFORE gn_edgeconv_bwd of the same layer (it also
+ * records the first-relu bits that gn_edgeconv_bwd consumes). */
+int32_t gn_edgeconv_dw2_slabs(int32_t mode, int32_t N, int32_t K, int32_t H1p, int32_t H2);
+int gn_edgeconv_dw2(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
+                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H1,
+                    int32_t H2, const float* gout, int64_t ldg, void* saved,
+                    float* slab, float* db2_part, void* stream);
 /* dP[N,H1p] (fp32, pitch ldp) and dpre rows T[(N*S+N), H1p]; W2Tp: T[ceil128(H1p)][H2p] */
 int gn_edgeconv_bwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
                     const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H2,
-                    const float* gout, int64_t ldg, const uint32_t* maskbits, const void* W2Tp, int32_t H2p,
+                    const float* gout, int64_t ldg, const void* saved, const void* W2Tp, int32_t H2p,
                     void* dpre, float* dP, int64_t ldp, void* stream);
-/* slab[splits][H2][H1] and db2_part[splits][H2] partials (reduce with gn_reduce_slabs) */
-int32_t gn_edgeconv_dw2_splits(int64_t rows);
-int gn_edgeconv_dw2(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
-                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H1,
-                    int32_t H2, const float* gout, int64_t ldg, const uint32_t* maskbits,
-                    float* slab, float* db2_part, int32_t splits, void* stream);
 /* dQ[j] = sum of dpre rows that gathered from j (ascending row id) */
 int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int32_t* rev_ptr,
                           const int32_t* rev_rows, int32_t N, float* dQ, int64_t ldq, void* stream);

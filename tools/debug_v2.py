@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""A/B debug: persistent (v2) vs generic (v1) bf16 EdgeConv kernels on identical inputs."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphnet_amd import ops
+from graphnet_amd.synthetic import synthetic_icecube86_batch
+
+dev, mode, dt = "cuda", 1, torch.bfloat16
+F, H1, H2 = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (256, 336, 256)))
+b = synthetic_icecube86_batch(40, seed=12)
+b.x[3:17, :3] = b.x[2, :3]
+b = b.to(dev)
+g = ops.knn_graph(b.x, [0, 1, 2], b.batch.to(torch.int32), b.ptr.to(torch.int32), 8)
+N, H1p = g.N, ops.round_up(H1, 32)
+torch.manual_seed(0)
+x = torch.randn(N, F, device=dev)
+W1 = torch.randn(H1, 2 * F, device=dev) * 0.05
+W2 = torch.randn(H2, H1, device=dev) * 0.05
+b2 = torch.randn(H2, device=dev) * 0.1
+Wpq = torch.zeros(2 * H1p, F, device=dev)
+Wpq[:H1] = W1[:, :F] - W1[:, F:]
+Wpq[H1p:H1p + H1] = W1[:, F:]
+PQ = ops.linear_fwd(mode, [(x, F)], ops.pack_weight(Wpq, [F], dt), 2 * H1p, out_lowp=True)
+W2p, W2Tp = ops.pack_weight(W2, [H1], dt), ops.pack_weight(W2.t().contiguous(), [H2], dt)
+gout = torch.randn(N, H2, device=dev)
+res = {}
+for tag, flag in (("v2", "0"), ("v1", "1")):
+    os.environ["GN_DISABLE_V2"] = flag
+    out, saved = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2)
+    dW2, db2 = ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, gout, saved)
+    dPQ = torch.zeros(N, 2 * H1p, device=dev)
+    dpre = torch.zeros(g.rows, H1p, dtype=dt, device=dev)
+    ops.edgeconv_bwd(mode, g, PQ, H1p, H2, gout, saved, W2Tp, dpre, dPQ[:, :H1p])
+    ops.edgeconv_dq_gather(mode, g, dpre, H1p, dPQ[:, H1p:])
+    torch.cuda.synchronize()
+    res[tag] = dict(out=out, dW2=dW2, db2=db2, dP=dPQ[:, :H1p].clone(), dQ=dPQ[:, H1p:].clone(), dpre=dpre.float())
+def rel(a, c): return float((a - c).abs().max() / c.abs().max().clamp_min(1e-30))
+for k in ("out", "dW2", "db2", "dP", "dQ"):
+    print(k, rel(res["v2"][k], res["v1"][k]))
+a, c = res["v2"]["dpre"][: N * 8], res["v1"]["dpre"][: N * 8]
+print("dpre main", rel(a, c))
+bad = ((a - c).abs() > 1e-2 * c.abs().max())
+print("bad fraction per 32-col block:", [round(float(bad[:, i * 32:(i + 1) * 32].float().mean()), 4) for i in range(H1p // 32)])
+print("bad fraction per row%64 (first 16):", [round(float(bad[i::64].float().mean()), 4) for i in range(16)])
+# hbits check
+nb = int(ops._lib.lib().gn_edgeconv_saved_bytes(N, 8, H1p, H2))
+lay_maskB = ((N * 8 + N) * (H2 // 32) * 4 + 255) // 256 * 256
+lay_hbits = lay_maskB + (N * H2 + 255) // 256 * 256
+os.environ["GN_DISABLE_V2"] = "0"
+out, saved = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2)
+ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, gout, saved)
+torch.cuda.synchronize()
+hb = saved[lay_hbits: lay_hbits + N * 8 * (H1p // 8)].view(N * 8, H1p // 8).cpu()
+nbr = g.nbr.cpu().long()
+P, Q = PQ[:, :H1p].float().cpu(), PQ[:, H1p:].float().cpu()
+rows = torch.arange(N * 8)
+ic, sl = rows // 8, rows % 8
+jc = nbr[ic, sl]
+valid = jc >= 0
+h = (P[ic] + Q[jc.clamp_min(0)]).to(torch.bfloat16).float().relu()
+bits = torch.zeros(N * 8, H1p, dtype=torch.bool)
+for c in range(H1p):
+    bits[:, c] = (hb[:, c // 8] >> (c % 8)) & 1 > 0
+print("hbits mismatch fraction (valid rows):", float(((h > 0) != bits)[valid].float().mean()))
+# ---- torch reference of dh / dpre for the first tile rows
+W2b = W2.to(dt).float().cpu()
+m_pre = h[:, :H1] @ W2b.t() + b2.cpu()
+mbit = (m_pre > 0).float()
+dm = (gout.cpu()[ic] * mbit).to(dt).float()
+dh = dm @ W2b
+dpre_ref = dh * (h[:, :H1] > 0).float()
+v2d = res["v2"]["dpre"][: N * 8, :H1].cpu()
+v1d = res["v1"]["dpre"][: N * 8, :H1].cpu()
+for r_ in range(10):
+    e2 = float((v2d[r_] - dpre_ref[r_]).abs().max() / dpre_ref[r_].abs().max().clamp_min(1e-9))
+    e1 = float((v1d[r_] - dpre_ref[r_]).abs().max() / dpre_ref[r_].abs().max().clamp_min(1e-9))
+    eu = float((v2d[r_] - dh[r_]).abs().max() / dh[r_].abs().max().clamp_min(1e-9))
+    # does v2 row r equal the reference of some other row?
+    d = (dpre_ref[:64] - v2d[r_]).abs().amax(1) / dpre_ref[:64].abs().amax(1).clamp_min(1e-9)
+    print("row", r_, "valid", bool(valid[r_]), "v2 err", round(e2, 4), "v1 err", round(e1, 4), "v2 vs unmasked dh", round(eu, 4),
+          "closest ref row", int(d.argmin()), round(float(d.min()), 4))

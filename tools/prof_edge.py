@@ -34,6 +34,7 @@ W2p = ops.pack_weight(W2, [H1], dt)
 W2Tp = ops.pack_weight(W2.t().contiguous(), [H2], dt)
 gout = torch.randn(N, H2, device=dev)
 out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2)
+ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, gout, mask)
 dPQ = torch.empty(N, 2 * H1p, device=dev)
 dpre = torch.empty(g.rows, H1p, dtype=dt, device=dev)
 torch.cuda.synchronize()
@@ -41,10 +42,10 @@ ops.enable_timers(True)
 for _ in range(iters):
     if what in ("fwd", "all"):
         ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2)
-    if what in ("bwd", "all"):
-        ops.edgeconv_bwd(mode, g, PQ, H1p, H2, gout, mask, W2Tp, dpre, dPQ[:, :H1p])
     if what in ("dw2", "all"):
         ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, gout, mask)
+    if what in ("bwd", "all"):
+        ops.edgeconv_bwd(mode, g, PQ, H1p, H2, gout, mask, W2Tp, dpre, dPQ[:, :H1p])
     if what in ("dq", "all"):
         ops.edgeconv_dq_gather(mode, g, dpre, H1p, dPQ[:, H1p:])
 print({k: (n, round(ms / n, 4)) for k, (n, ms) in ops.timer_summary().items()}, "N", N)
