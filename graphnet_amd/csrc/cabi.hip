@@ -109,7 +109,7 @@ int gn_linear_fwd(int32_t mode, int32_t nseg, const float* const* a_ptr, const i
     if (r == hipErrorInvalidValue) return bad("gn_linear_fwd", "segment widths/pitches must be multiples of 4, kpad multiples of 32 summing to Kp");
     return fail(r, "gn_linear_fwd");
 }
-int32_t gn_linear_wgrad_splits(int32_t M) { return gn::gemm_tn_splits(M); }
+int32_t gn_linear_wgrad_splits(int32_t M, int32_t tiles) { return gn::gemm_tn_splits_for(M, tiles); }
 int gn_linear_wgrad(int32_t mode, const float* dY, int64_t lddy, int32_t N1, int32_t nseg, const float* const* x_ptr,
                     const int64_t* x_ld, const int32_t* x_width, int32_t M, float* slab, float* dW, int32_t accum,
                     void* stream) {

@@ -75,6 +75,35 @@ __device__ __forceinline__ void mma_block(const unsigned char* a_tile, const uns
     }
 }
 
+// Same with an explicit K depth per LDS block (BKE elements): pitch BKE*sizeof(T)+16 bytes.
+template <typename T, int TM, int TN, int BKE>
+__device__ __forceinline__ void mma_block_k(const unsigned char* a_tile, const unsigned char* b_tile,
+                                            int a_row0, int b_row0, int lane, f32x16 (&acc)[TM][TN]) {
+    constexpr int ROWB = BKE * (int)sizeof(T) + 16;
+    constexpr int KSTEPS = BKE * (int)sizeof(T) / 32;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        Frag<T> fa[TM], fb[TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const unsigned char* p = a_tile + (a_row0 + m * 32 + r) * ROWB + s * 32 + h * 16;
+            if constexpr (sizeof(T) == 4) fa[m].v = *reinterpret_cast<const f32x4*>(p);
+            else fa[m].v = *reinterpret_cast<const bf16x8*>(p);
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const unsigned char* p = b_tile + (b_row0 + n * 32 + r) * ROWB + s * 32 + h * 16;
+            if constexpr (sizeof(T) == 4) fb[n].v = *reinterpret_cast<const f32x4*>(p);
+            else fb[n].v = *reinterpret_cast<const bf16x8*>(p);
+        }
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) mma(fa[m], fb[n], acc[m][n]);
+    }
+}
+
 // ---- scalar/vector conversions -------------------------------------------------------
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }

@@ -19,13 +19,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <typename T, int BM, int BN, typename OutT>
+template <typename T, int BM, int BN, int BKE, typename OutT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __restrict__ Wp, int Kp, int Nreal,
                                                       Epi epi, OutT* __restrict__ C, long long ldc, int ntn) {
-    constexpr int ROWB = TileCfg<T>::ROWB;
+    constexpr int ROWB = BKE * (int)sizeof(T) + 16;            // padded LDS row pitch
     constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int ACH = BM / 32;                               // float4 loads of A per thread
-    constexpr int BCHROW = BK * (int)sizeof(T) / 16;           // 16-byte chunks per W row
+    constexpr int ACOLT = BKE / 4;                             // threads covering one A row (float4 each)
+    constexpr int AROWS = 256 / ACOLT;                         // A rows covered per pass
+    constexpr int ACH = BM / AROWS;                            // float4 loads of A per thread
+    constexpr int BCHROW = BKE * (int)sizeof(T) / 16;          // 16-byte chunks per W row
     constexpr int BCH = BN * BCHROW / 256;
     __shared__ __attribute__((aligned(16))) unsigned char As[BM * ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * ROWB];
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __
 #pragma unroll
         for (int j = 0; j < TN; ++j) zero_acc(acc[i][j]);
 
-    const int c4 = (tid & 7) * 4, r0 = tid >> 3;
+    const int c4 = (tid % ACOLT) * 4, r0 = tid / ACOLT;
     float4 areg[ACH];
     u32x4 breg[BCH];
 
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __
     {                                                                                                    \
         const bool colok = (kin + c4) < awidth;                                                          \
         _Pragma("unroll") for (int i = 0; i < ACH; ++i) {                                                \
-            const int row = m0 + r0 + 32 * i;                                                            \
+            const int row = m0 + r0 + AROWS * i;                                                         \
             areg[i] = (colok && row < M)                                                                 \
                           ? *reinterpret_cast<const float4*>(ap + (long long)row * ald + kin + c4)       \
                           : make_float4(0.f, 0.f, 0.f, 0.f);                                             \
@@ -67,13 +69,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __
     }
     const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(Wp);
 
-    const int nkb = Kp / BK;
+    const int nkb = Kp / BKE;
     GN_GEMM_LOAD_REGS();
     for (int kb = 0; kb < nkb; ++kb) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < ACH; ++i)
-            store4<T>(As + (r0 + 32 * i) * ROWB + c4 * sizeof(T), areg[i].x, areg[i].y, areg[i].z, areg[i].w);
+            store4<T>(As + (r0 + AROWS * i) * ROWB + c4 * sizeof(T), areg[i].x, areg[i].y, areg[i].z, areg[i].w);
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             const int ch = tid + 256 * i;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __
         }
         __syncthreads();
         if (kb + 1 < nkb) {
-            kin += BK; kglob += BK;
+            kin += BKE; kglob += BKE;
             if (kin >= akpad) {
                 kin = 0; ++seg;
 #pragma unroll
@@ -90,24 +92,46 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __
             }
             GN_GEMM_LOAD_REGS();
         }
-        mma_block<T, TM, TN>(As, Bs, wr * (BM / 2), wc * (BN / 2), lane, acc);
+        mma_block_k<T, TM, TN, BKE>(As, Bs, wr * (BM / 2), wc * (BN / 2), lane, acc);
     }
 
 #undef GN_GEMM_LOAD_REGS
+    // ---- epilogue.  K is short on this path (256..1056), so the epilogue's instruction count matters as
+    // much as the main loop: interior tiles take a predicate-free path with hoisted row pointers.
     const int h = lane >> 5, cl = lane & 31;
+    const float lo = epi.relu ? 0.0f : -3.0e38f;
+    const int rowb = m0 + wr * (BM / 2) + 4 * h;
+    const int colb = n0 + wc * (BN / 2) + cl;
+    const bool interior = (m0 + BM <= M) && (n0 + BN <= Nreal);        // workgroup-uniform
+    if (interior && !epi.gate && !epi.accum) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = colb + j * 32;
+            const float b = epi.bias ? epi.bias[col] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                OutT* base = C + (long long)(rowb + i * 32) * ldc + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = fmaxf(acc[i][j][r] + b, lo);
+                    base[(long long)acc_row(r, 0) * ldc] = from_f32<OutT>(v);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wc * (BN / 2) + j * 32 + cl;
+            const int col = colb + j * 32;
             if (col >= Nreal) continue;
             const float b = epi.bias ? epi.bias[col] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * (BM / 2) + i * 32 + acc_row(r, h);
+                const int row = rowb + i * 32 + acc_row(r, 0);
                 if (row >= M) continue;
-                float v = acc[i][j][r] + b;
-                if (epi.relu) v = fmaxf(v, 0.0f);
+                float v = fmaxf(acc[i][j][r] + b, lo);
                 if (epi.gate && !(epi.gate[(long long)row * epi.ldgate + col] > 0.0f)) v = 0.0f;
                 OutT* dst = C + (long long)row * ldc + col;
                 if constexpr (sizeof(OutT) == 4) {
@@ -219,16 +243,46 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     out[i] = accum ? out[i] + s : s;
 }
 
-// part[blk][c] = sum over rows of block blk of X[r][c]
-constexpr int COLSUM_ROWS = 512;
+// part[blk][c] = sum over the rows of block blk of X[r][c].  Rows are streamed as whole 16-byte
+// chunks (lane = 4 columns), the 4 waves of a block take interleaved rows and are combined
+// through LDS in fixed order -> coalesced and deterministic.  HBM-bound: M*C*4 bytes read.
+constexpr int COLSUM_ROWS = 256;
+constexpr int COLSUM_MAXC = 1024;          // columns handled per launch (4 x 256 per lane group)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long long ld, int M, int C,
                                                      float* __restrict__ part) {
+    __shared__ float red[4][COLSUM_MAXC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rbeg = blockIdx.x * COLSUM_ROWS, rend = min(M, rbeg + COLSUM_ROWS);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.0f;
-        for (int r = rbeg; r < rend; ++r) s += X[(long long)r * ld + c];
-        part[(long long)blockIdx.x * C + c] = s;
+    f32x4 acc[COLSUM_MAXC / 256];
+#pragma unroll
+    for (int j = 0; j < COLSUM_MAXC / 256; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // 8 rows (x up to 4 column groups) of loads in flight per wave: streaming, not latency-bound
+    for (int r0 = rbeg + wave; r0 < rend; r0 += 32) {
+        f32x4 v[8][COLSUM_MAXC / 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 4 * u;
+            const float* row = X + (long long)(r < rend ? r : rbeg) * ld;
+#pragma unroll
+            for (int j = 0; j < COLSUM_MAXC / 256; ++j) {
+                const int c = j * 256 + lane * 4;
+                v[u][j] = (c < C) ? *reinterpret_cast<const f32x4*>(row + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < COLSUM_MAXC / 256; ++j)
+                if (r0 + 4 * u < rend) acc[j] += v[u][j];
     }
+#pragma unroll
+    for (int j = 0; j < COLSUM_MAXC / 256; ++j) {
+        const int c = j * 256 + lane * 4;
+        if (c < C) *reinterpret_cast<f32x4*>(&red[wave][c]) = acc[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        part[(long long)blockIdx.x * C + c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
 }
 
 }  // namespace gn
@@ -238,17 +292,35 @@ namespace gn {
 
 static inline int cdiv_(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+template <typename T, int BN, int BKE, typename OutT>
+static hipError_t launch_gemm_nt_cfg(const Segs& a, int M, const void* Wp, int Kp, int Npad, int Nreal, const Epi& epi,
+                                     void* C, long long ldc, hipStream_t st) {
+    constexpr int BM = 128;
+    const int ntn = cdiv_(Nreal, BN);
+    if (ntn * BN > Npad) return hipErrorInvalidValue;
+    const int ntm = cdiv_(M, BM);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, BKE, OutT>), dim3(ntm * ntn), dim3(256), 0, st, a, M,
+                       reinterpret_cast<const T*>(Wp), Kp, Nreal, epi, reinterpret_cast<OutT*>(C), ldc, ntn);
+    return hipGetLastError();
+}
+
 template <typename T, typename OutT>
 static hipError_t launch_gemm_nt_t(const Segs& a, int M, const void* Wp, int Kp, int Npad, int Nreal, const Epi& epi,
                                    void* C, long long ldc, hipStream_t st) {
     if (M == 0) return hipSuccess;
-    constexpr int BM = 128, BN = 128;
-    const int ntn = cdiv_(Nreal, BN);
-    if (ntn * BN > Npad) return hipErrorInvalidValue;
-    const int ntm = cdiv_(M, BM);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, OutT>), dim3(ntm * ntn), dim3(256), 0, st, a, M,
-                       reinterpret_cast<const T*>(Wp), Kp, Nreal, epi, reinterpret_cast<OutT*>(C), ldc, ntn);
-    return hipGetLastError();
+    if constexpr (sizeof(T) == 2) {
+        // bf16: 64-deep LDS blocks when every segment allows it (twice the MFMAs per barrier) and a
+        // 256-wide N tile when that does not add padding (A is staged once for all of it)
+        bool k64 = (Kp % 64) == 0;
+        for (int s = 0; s < a.nseg; ++s) k64 = k64 && (a.kpad[s] % 64) == 0;
+        static const bool allow_wide = !(getenv("GN_GEMM_WIDE") && getenv("GN_GEMM_WIDE")[0] == '0');
+        static const bool allow_k64 = !(getenv("GN_GEMM_K64") && getenv("GN_GEMM_K64")[0] == '0');
+        k64 = k64 && allow_k64;
+        const bool wide = allow_wide && cdiv_(Nreal, 256) * 256 <= cdiv_(Nreal, 128) * 128 && cdiv_(Nreal, 256) * 256 <= Npad;
+        if (k64 && wide) return launch_gemm_nt_cfg<T, 256, 64, OutT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+        if (k64) return launch_gemm_nt_cfg<T, 128, 64, OutT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+    }
+    return launch_gemm_nt_cfg<T, 128, 32, OutT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
 }
 
 // mode: 0 = f32 operands, 1 = bf16 operands.  out_lowp: write C in the operand type.
@@ -265,8 +337,11 @@ hipError_t launch_gemm_nt(int mode, const Segs& a, int M, const void* Wp, int Kp
     return launch_gemm_nt_t<__bf16, float>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
 }
 
-int gemm_tn_splits(int M) {
-    int s = cdiv_(M, 2048);
+// splits over the contraction (rows): aim at ~1024 workgroups in total, at least 512 rows per split
+int gemm_tn_splits_for(int M, int tiles) {
+    int s = cdiv_(1024, tiles > 0 ? tiles : 1);
+    const int smax = cdiv_(M > 0 ? M : 1, 512);
+    if (s > smax) s = smax;
     if (s < 1) s = 1;
     if (s > 256) s = 256;
     return s;
@@ -282,7 +357,7 @@ hipError_t launch_gemm_tn(int mode, const float* dY, long long lddy, int N1, con
         ktiles += cdiv_(x.width[s], 128);
     }
     if ((lddy & 3) || (N1 & 3)) return hipErrorInvalidValue;
-    const int splits = gemm_tn_splits(M);
+    const int splits = gemm_tn_splits_for(M, cdiv_(N1, 128) * ktiles);
     int rps = cdiv_(M > 0 ? M : 1, splits);
     rps = cdiv_(rps, BK) * BK;
     const int n1t = cdiv_(N1, 128);
@@ -300,6 +375,7 @@ int colsum_blocks(int M) { return cdiv_(M > 0 ? M : 1, COLSUM_ROWS); }
 
 // out[c] (+)= sum_r X[r][c];  part: >= colsum_blocks(M)*C floats
 hipError_t launch_colsum(const float* X, long long ld, int M, int C, float* part, float* out, int accum, hipStream_t st) {
+    if ((C & 3) || (ld & 3) || C > COLSUM_MAXC || (reinterpret_cast<uintptr_t>(X) & 15)) return hipErrorInvalidValue;
     const int nb = colsum_blocks(M);
     hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, X, ld, M, C, part);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(C, 256)), dim3(256), 0, st, part, nb, (long long)C, out, accum);

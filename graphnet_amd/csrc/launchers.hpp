@@ -24,7 +24,7 @@ hipError_t launch_ptr_to_batch(const int* ptr, int B, int* batch, hipStream_t st
 // gemm.hip
 hipError_t launch_gemm_nt(int mode, const Segs& a, int M, const void* Wp, int Kp, int Npad, int Nreal, const Epi& epi,
                           void* C, long long ldc, int out_lowp, hipStream_t st);
-int gemm_tn_splits(int M);
+int gemm_tn_splits_for(int M, int tiles);
 hipError_t launch_gemm_tn(int mode, const float* dY, long long lddy, int N1, const Segs& x, int M, float* slab,
                           float* dW, int accum, hipStream_t st);
 int colsum_blocks(int M);

@@ -16,33 +16,46 @@ __global__ __launch_bounds__(256) void segment_pool_fwd_kernel(
     const float* __restrict__ x, long long ldx, int C, const int* __restrict__ ptr, int B,
     PoolSchemes sch, float* __restrict__ out /*[B, n*C]*/, int* __restrict__ argmin, int* __restrict__ argmax)
 {
+    // grid.x = event, grid.y = 256-column group; thread = column; 4 independent rows in flight
     const int g = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
     const int lo = ptr[g], hi = ptr[g + 1];
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float mn = 0.0f, mx = 0.0f, sm = 0.0f;
-        int amn = -1, amx = -1;
-        if (hi > lo) {
-            mn = mx = sm = x[(long long)lo * ldx + c];
-            amn = amx = lo;
-            for (int i = lo + 1; i < hi; ++i) {
-                const float v = x[(long long)i * ldx + c];
-                sm += v;
-                if (v < mn) { mn = v; amn = i; }
-                if (v > mx) { mx = v; amx = i; }
-            }
-        }
-        const float mean = sm / (float)max(hi - lo, 1);
+    float mn = 0.0f, mx = 0.0f, sm = 0.0f;
+    int amn = -1, amx = -1;
+    if (hi > lo) {
+        mn = mx = sm = x[(long long)lo * ldx + c];
+        amn = amx = lo;
+        int i = lo + 1;
+        for (; i + 3 < hi; i += 4) {
+            float v[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < sch.n) {
-                const int code = sch.code[s];
-                const float v = code == 0 ? mn : (code == 1 ? mx : (code == 2 ? sm : mean));
-                out[((long long)g * sch.n + s) * C + c] = v;
+            for (int u = 0; u < 4; ++u) v[u] = x[(long long)(i + u) * ldx + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sm += v[u];
+                if (v[u] < mn) { mn = v[u]; amn = i + u; }
+                if (v[u] > mx) { mx = v[u]; amx = i + u; }
             }
         }
-        if (argmin) argmin[(long long)g * C + c] = amn;
-        if (argmax) argmax[(long long)g * C + c] = amx;
+        for (; i < hi; ++i) {
+            const float v = x[(long long)i * ldx + c];
+            sm += v;
+            if (v < mn) { mn = v; amn = i; }
+            if (v > mx) { mx = v; amx = i; }
+        }
     }
+    const float mean = sm / (float)max(hi - lo, 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s < sch.n) {
+            const int code = sch.code[s];
+            const float v = code == 0 ? mn : (code == 1 ? mx : (code == 2 ? sm : mean));
+            out[((long long)g * sch.n + s) * C + c] = v;
+        }
+    }
+    if (argmin) argmin[(long long)g * C + c] = amn;
+    if (argmax) argmax[(long long)g * C + c] = amx;
 }
 
 // dx[i][c] = gate(i,c) * ( g_sum + g_mean / n + [i == argmin] g_min + [i == argmax] g_max )
@@ -79,7 +92,7 @@ hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr,
     PoolSchemes s;
     s.n = ns;
     for (int i = 0; i < 4; ++i) s.code[i] = i < ns ? codes[i] : 0;
-    hipLaunchKernelGGL(segment_pool_fwd_kernel, dim3(B), dim3(256), 0, st, x, ldx, C, ptr, B, s, out, argmin, argmax);
+    hipLaunchKernelGGL(segment_pool_fwd_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, st, x, ldx, C, ptr, B, s, out, argmin, argmax);
     return hipGetLastError();
 }
 

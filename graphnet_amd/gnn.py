@@ -94,6 +94,7 @@ class _DynEdgeFunction(torch.autograd.Function):
     def forward(ctx, cfg: dict, x: Tensor, *params: Tensor) -> Tensor:  # type: ignore[override]
         mode = cfg["mode"]
         dt = ops.mode_dtype(mode)
+        ku = ops.gemm_kunit(mode)
         lowp = mode == ops.MODE_BF16
         batch, ptr, g = cfg["batch"], cfg["ptr"], cfg["graph"]
         nconv, npost = cfg["nconv"], cfg["npost"]
@@ -117,7 +118,7 @@ class _DynEdgeFunction(torch.autograd.Function):
             Wpq[H1p:H1p + H1] = Wb
             bpq = torch.zeros(2 * H1p, dtype=torch.float32, device=x.device)
             bpq[:H1] = b1
-            PQ = ops.linear_fwd(mode, [(xin, _kw(Fin))], ops.pack_weight(Wpq, [Fin], dt), 2 * H1p, bias=bpq,
+            PQ = ops.linear_fwd(mode, [(xin, _kw(Fin))], ops.pack_weight(Wpq, [Fin], dt, ku), 2 * H1p, bias=bpq,
                                 out_lowp=lowp)
             out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, ops.pack_weight(W2, [H1], dt), b2.contiguous(), H2)
             graphs.append(g); PQs.append(PQ); masks.append(mask)
@@ -128,7 +129,7 @@ class _DynEdgeFunction(torch.autograd.Function):
         ys: List[Tuple[Tensor, int]] = []
         segs = xs
         for (W, b) in post_p:
-            y = ops.linear_fwd(mode, _ksegs(segs), ops.pack_weight(W, [w for _, w in segs], dt), int(W.shape[0]),
+            y = ops.linear_fwd(mode, _ksegs(segs), ops.pack_weight(W, [w for _, w in segs], dt, ku), int(W.shape[0]),
                                bias=b.contiguous(), relu=True)
             ys.append((y, int(W.shape[0])))
             segs = [ys[-1]]
@@ -147,6 +148,7 @@ class _DynEdgeFunction(torch.autograd.Function):
         cfg = ctx.cfg
         mode = cfg["mode"]
         dt = ops.mode_dtype(mode)
+        ku = ops.gemm_kunit(mode)
         batch, ptr = cfg["batch"], cfg["ptr"]
         nconv, npost = cfg["nconv"], cfg["npost"]
         params = ctx.params
@@ -177,14 +179,14 @@ class _DynEdgeFunction(torch.autograd.Function):
             grads[4 * nconv + 2 * t + 1] = ops.colsum(dZ, Pt)
             if t > 0:
                 yprev, Pprev = ys[t - 1]
-                dZ = ops.linear_fwd(mode, [(dZ, Pt)], ops.pack_weight(W.t(), [Pt], dt), Pprev, gate=yprev)
+                dZ = ops.linear_fwd(mode, [(dZ, Pt)], ops.pack_weight(W.t(), [Pt], dt, ku), Pprev, gate=yprev)
             else:
                 WT = torch.zeros((sum(seg_pad), Pt), dtype=torch.float32, device=dev)
                 off = 0
                 for s, (_, w) in enumerate(xs):
                     WT[seg_off[s]: seg_off[s] + w] = W[:, off: off + w].t()
                     off += w
-                dXcat = ops.linear_fwd(mode, [(dZ, Pt)], ops.pack_weight(WT, [Pt], dt), sum(seg_pad))
+                dXcat = ops.linear_fwd(mode, [(dZ, Pt)], ops.pack_weight(WT, [Pt], dt, ku), sum(seg_pad))
 
         # ---- DynEdgeConv layers, last first
         for l in reversed(range(nconv)):
@@ -211,7 +213,7 @@ class _DynEdgeFunction(torch.autograd.Function):
                 WpqT = torch.zeros((Fin, 2 * H1p), dtype=torch.float32, device=dev)
                 WpqT[:, :H1] = (Wa - Wb).t()
                 WpqT[:, H1p:H1p + H1] = Wb.t()
-                ops.linear_fwd(mode, [(dPQ, 2 * H1p)], ops.pack_weight(WpqT, [2 * H1p], dt), Fin,
+                ops.linear_fwd(mode, [(dPQ, 2 * H1p)], ops.pack_weight(WpqT, [2 * H1p], dt, ku), Fin,
                                out=dXcat[:, seg_off[l]: seg_off[l] + Fin], accum=True)
         return (None, None) + tuple(grads)
 

@@ -219,24 +219,30 @@ def concat_globals(x: Tensor, gv: Optional[Tensor], batch: Tensor, ld0: int) -> 
 Seg = Tuple[Tensor, int]   # (fp32 tensor [M, >=width] with unit column stride, real width)
 
 
-def _seg_arrays(segs: Sequence[Seg], with_kpad: bool):
+def gemm_kunit(mode: int) -> int:
+    """K padding unit of the per-node GEMM operands: bf16 uses 64-deep LDS blocks."""
+    return 64 if mode == MODE_BF16 else 32
+
+
+def _seg_arrays(segs: Sequence[Seg], with_kpad: bool, kunit: int = 32):
     n = len(segs)
     ptrs = (ctypes.c_void_p * n)(*[s[0].data_ptr() for s in segs])
     lds = (ctypes.c_int64 * n)(*[_rows(s[0], "segment") for s in segs])
     widths = (ctypes.c_int32 * n)(*[int(s[1]) for s in segs])
-    kpads = (ctypes.c_int32 * n)(*[round_up(int(s[1]), 32) for s in segs]) if with_kpad else None
+    kpads = (ctypes.c_int32 * n)(*[round_up(int(s[1]), kunit) for s in segs]) if with_kpad else None
     for s in segs:
         _need(s[0], torch.float32, "segment")
     return n, ptrs, lds, widths, kpads
 
 
-def pack_weight(W: Tensor, seg_widths: Sequence[int], dtype: torch.dtype) -> Tensor:
-    """``W[N, sum widths]`` fp32 -> ``[ceil128(N)][sum ceil32(width)]`` of ``dtype`` (zero padded)."""
+def pack_weight(W: Tensor, seg_widths: Sequence[int], dtype: torch.dtype, kunit: int = 32) -> Tensor:
+    """``W[N, sum widths]`` fp32 -> ``[ceil128(N)][sum ceil_kunit(width)]`` of ``dtype`` (zero padded).
+    ``kunit`` = 32 for the EdgeConv kernels' operands, :func:`gemm_kunit` for :func:`linear_fwd`."""
     N = int(W.shape[0])
     parts, off = [], 0
     for w in seg_widths:
         blk = W[:, off:off + w]
-        parts.append(torch.nn.functional.pad(blk, (0, round_up(w, 32) - w)))
+        parts.append(torch.nn.functional.pad(blk, (0, round_up(w, kunit) - w)))
         off += w
     Wp = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
     Wp = torch.nn.functional.pad(Wp, (0, 0, 0, round_up(N, 128) - N))
@@ -246,8 +252,9 @@ def pack_weight(W: Tensor, seg_widths: Sequence[int], dtype: torch.dtype) -> Ten
 def linear_fwd(mode: int, segs: Sequence[Seg], Wp: Tensor, n_real: int, bias: Optional[Tensor] = None,
                relu: bool = False, gate: Optional[Tensor] = None, out: Optional[Tensor] = None,
                accum: bool = False, out_lowp: bool = False, out_cols: Optional[int] = None) -> Tensor:
-    """``out[M, n_real] = epi(cat(segs) @ W^T + bias)`` on MFMA.  ``Wp`` from :func:`pack_weight`."""
-    n, ptrs, lds, widths, kpads = _seg_arrays(segs, True)
+    """``out[M, n_real] = epi(cat(segs) @ W^T + bias)`` on MFMA.  ``Wp`` from
+    ``pack_weight(W, widths, dtype, kunit=gemm_kunit(mode))``."""
+    n, ptrs, lds, widths, kpads = _seg_arrays(segs, True, gemm_kunit(mode))
     M = int(segs[0][0].shape[0])
     Npad, Kp = int(Wp.shape[0]), int(Wp.shape[1])
     if out is None:
@@ -272,7 +279,8 @@ def linear_wgrad(mode: int, dY: Tensor, n1: int, segs: Sequence[Seg], out: Optio
     M = int(dY.shape[0])
     ktot = sum(int(s[1]) for s in segs)
     L = _lib.lib()
-    splits = int(L.gn_linear_wgrad_splits(M))
+    tiles = ((n1 + 127) // 128) * sum((int(s[1]) + 127) // 128 for s in segs)
+    splits = int(L.gn_linear_wgrad_splits(M, tiles))
     slab = torch.empty(splits * n1 * ktot, dtype=torch.float32, device=dY.device)
     if out is None:
         out = torch.empty((n1, ktot), dtype=torch.float32, device=dY.device)

@@ -86,8 +86,9 @@ int gn_linear_fwd(int32_t mode, int32_t nseg, const float* const* a_ptr, const i
                   const float* bias, const float* gate, int64_t ldgate, int32_t relu, int32_t accum,
                   void* C, int64_t ldc, int32_t out_lowp, void* stream);
 
-/* dW[N1, sum width_s] (+)= dY[M,N1]^T . [X_0 | X_1 | ...]; slab: >= gn_linear_wgrad_splits(M)*N1*Ktot floats */
-int32_t gn_linear_wgrad_splits(int32_t M);
+/* dW[N1, sum width_s] (+)= dY[M,N1]^T . [X_0 | X_1 | ...]; slab: >= gn_linear_wgrad_splits(M, tiles)*N1*Ktot
+ * floats with tiles = ceil(N1/128) * sum_s ceil(width_s/128) */
+int32_t gn_linear_wgrad_splits(int32_t M, int32_t tiles);
 int gn_linear_wgrad(int32_t mode, const float* dY, int64_t lddy, int32_t N1, int32_t nseg,
                     const float* const* x_ptr, const int64_t* x_ld, const int32_t* x_width, int32_t M,
                     float* slab, float* dW, int32_t accum, void* stream);

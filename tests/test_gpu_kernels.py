@@ -166,7 +166,7 @@ def test_linear_fwd_segments_and_epilogues(name, mode, tol):
     for (x, wp), w in zip(segs, widths):
         Wfull[:, offp:offp + w] = W[:, off:off + w]
         off += w; offp += wp
-    Wp = ops.pack_weight(Wfull.to(DEV), [s[1] for s in segs], ops.mode_dtype(mode))
+    Wp = ops.pack_weight(Wfull.to(DEV), [s[1] for s in segs], ops.mode_dtype(mode), ops.gemm_kunit(mode))
     y = ops.linear_fwd(mode, segs, Wp, 336, bias=bias.to(DEV))
     assert rel_err(y, ref) < tol, f"{name}: plain"
     y = ops.linear_fwd(mode, segs, Wp, 336, bias=bias.to(DEV), relu=True)
@@ -231,7 +231,7 @@ def test_edgeconv_forward(oracle, name, mode, tol, k, F, H1, H2):
     Wpq[:H1] = W1[:, :F] - W1[:, F:]
     Wpq[H1p:H1p + H1] = W1[:, F:]
     bpq = torch.zeros(2 * H1p, device=DEV); bpq[:H1] = b1
-    PQ = ops.linear_fwd(mode, [(x.to(DEV), F)], ops.pack_weight(Wpq, [F], dt), 2 * H1p, bias=bpq, out_lowp=(mode == 1))
+    PQ = ops.linear_fwd(mode, [(x.to(DEV), F)], ops.pack_weight(Wpq, [F], dt, ops.gemm_kunit(mode)), 2 * H1p, bias=bpq, out_lowp=(mode == 1))
     out, _mask = ops.edgeconv_fwd(mode, t, PQ, H1p, ops.pack_weight(W2, [H1], dt), b2, H2)
     assert rel_err(out, ref) < tol, name
 
@@ -308,7 +308,7 @@ def test_persistent_kernels_match_generic_kernels(oracle):
         Wpq[:H1] = W1[:, :F] - W1[:, F:]
         Wpq[H1p:H1p + H1] = W1[:, F:]
         bpq = torch.zeros(2 * H1p, device=DEV); bpq[:H1] = b1
-        PQ = ops.linear_fwd(mode, [(x.to(DEV), F)], ops.pack_weight(Wpq, [F], dt), 2 * H1p, bias=bpq, out_lowp=True)
+        PQ = ops.linear_fwd(mode, [(x.to(DEV), F)], ops.pack_weight(Wpq, [F], dt, ops.gemm_kunit(mode)), 2 * H1p, bias=bpq, out_lowp=True)
         W2p, W2Tp = ops.pack_weight(W2, [H1], dt), ops.pack_weight(W2.t().contiguous(), [H2], dt)
         torch.manual_seed(5)
         gout = torch.randn(N, H2, device=DEV)

@@ -21,7 +21,7 @@ b2 = torch.randn(H2, device=dev) * 0.1
 Wpq = torch.zeros(2 * H1p, F, device=dev)
 Wpq[:H1] = W1[:, :F] - W1[:, F:]
 Wpq[H1p:H1p + H1] = W1[:, F:]
-PQ = ops.linear_fwd(mode, [(x, F)], ops.pack_weight(Wpq, [F], dt), 2 * H1p, out_lowp=True)
+PQ = ops.linear_fwd(mode, [(x, F)], ops.pack_weight(Wpq, [F], dt, ops.gemm_kunit(mode)), 2 * H1p, out_lowp=True)
 W2p, W2Tp = ops.pack_weight(W2, [H1], dt), ops.pack_weight(W2.t().contiguous(), [H2], dt)
 gout = torch.randn(N, H2, device=dev)
 res = {}
