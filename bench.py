@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--events", type=int, default=1024, help="events per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph (experimental) instead of eager launches")
+    ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-op HIP events (roofline)")
     ap.add_argument("--cpu-events", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
@@ -107,17 +109,29 @@ def main():
     model = build_model(args.dtype).to(dev)
     broadcast_parameters(model)
     sync = FlatGradAllReduce(model.parameters())
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-3, capturable=True)
     batch = synthetic_icecube86_batch(args.events, seed=20241016 + rank).to(dev)   # disjoint shards (weak scaling)
     n_nodes = int(batch.x.shape[0])
 
-    def step():
+    def eager_step():
         sync.zero_grad()
         loss = model.shared_step(batch)
         loss.backward()
         sync()
         opt.step()
         return loss
+
+    launch = "eager"
+    step = eager_step
+    if args.graph:
+        try:
+            from graphnet_amd.graphed import GraphedTrainStep
+            graphed = GraphedTrainStep(model, opt, sync)
+            graphed(batch)                                    # capture (+ its own eager warm-up)
+            step = lambda: graphed(batch)
+            launch = "hipgraph"
+        except Exception as exc:                              # pragma: no cover - reported, never silent
+            print(f"[bench] hipGraph capture failed, running eager: {exc!r}", file=sys.stderr)
 
     def fence():
         torch.cuda.synchronize()
@@ -128,14 +142,21 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ops.enable_timers(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    # per-kernel durations: HIP events on the launch stream around every C-ABI op.  A graph replay has
+    # no per-kernel events, so the same kernels are timed in a few eager steps right after the timed
+    # region (same process, same buffers); rocprofv3 --kernel-trace of this command must agree.
+    ops.enable_timers(True)
+    for _ in range(max(1, args.profile_steps)):
+        eager_step()
+    fence()
     timers = ops.timer_summary()
     ops.enable_timers(False)
+    prof_steps = max(1, args.profile_steps)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -161,7 +182,7 @@ def main():
             "edgeconv_dw2": 2.0 * n_edges * 256 * (3 * 336 + 128) / 4,
         }.get(name)
         if kernel_flops is None:                       # a per-node GEMM dominates: price the whole path instead
-            kernel_flops = 3.0 * flops_fwd / max(launches / args.steps, 1)
+            kernel_flops = 3.0 * flops_fwd / max(launches / prof_steps, 1)
         achieved = kernel_flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
         out = {
             "metric": "events/sec DynEdge fwd+bwd, IceCube-86 k=8",
@@ -174,11 +195,12 @@ def main():
                        "parallelism": f"dp{world} (event shards, one flat RCCL all-reduce)"},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
-                         "launch_ms": per_launch_ms, "launches_per_step": launches / args.steps},
+                         "launch_ms": per_launch_ms, "launches_per_step": launches / prof_steps},
             "path_roofline": {"algorithmic_tflop_per_step": 3.0 * flops_fwd * world / 1e12,
                               "achieved_tflops": 3.0 * flops_fwd * world * args.steps / dt / 1e12,
                               "frac_of_peak": 3.0 * flops_fwd * args.steps / dt / 1e12 / peak},
-            "phase_ms_per_step": {k: v[1] / args.steps for k, v in sorted(timers.items(), key=lambda kv: -kv[1][1])},
+            "phase_ms_per_step": {k: v[1] / prof_steps for k, v in sorted(timers.items(), key=lambda kv: -kv[1][1])},
+            "launch": launch,
             "final_loss": float(loss.detach()),
         }
         if world == 1 and not args.no_cpu_baseline:

