@@ -171,19 +171,44 @@ def main():
             n_edges = int((t.nbr >= 0).sum().item()) + int(t.ovf_cnt.item())
         flops_fwd = algorithmic_flops(n_nodes, n_edges, args.events)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        # dominant kernel (by HIP-event time on the launch stream) and its own algorithmic FLOPs
+        # dominant op group (by HIP-event time on the launch stream) priced with ITS OWN algorithmic work:
+        # MFMA groups in FLOPs (2*rows*K*N of the contraction it performs), HBM groups in bytes.
+        E, N = float(n_edges), float(n_nodes)
+        conv = [(19, 128, 256), (256, 336, 256), (256, 336, 256), (256, 336, 256)]       # (F_in, H1, H2)
+        F0 = 19
+        flops = {
+            "edgeconv_fwd": sum(2 * E * h1 * h2 for _, h1, h2 in conv),
+            "edgeconv_bwd": sum(2 * E * h1 * h2 for _, h1, h2 in conv),
+            "edgeconv_dw2": sum(2 * E * h1 * h2 for _, h1, h2 in conv),
+            # P|Q GEMMs, post MLP (2 layers), their input-gradient GEMMs, conv input gradients
+            "linear_fwd": sum(2 * N * f * 2 * h1 for f, h1, _ in conv) + 2 * N * ((F0 + 1024) * 336 + 336 * 256)
+                          + 2 * N * (336 * 256 + (F0 + 1024) * 336) + sum(2 * N * 2 * h1 * f for f, h1, _ in conv[1:]),
+            "linear_wgrad": sum(2 * N * f * 2 * h1 for f, h1, _ in conv) + 2 * N * ((F0 + 1024) * 336 + 336 * 256),
+        }
+        hbm_bytes = {   # algorithmic bytes per step of the HBM-bound groups (bf16 dpre rows, fp32 activations)
+            "edgeconv_dq_gather": sum(E * 2 * (h1 + 31) // 32 * 32 + N * 4 * h1 for _, h1, _ in conv),
+            "knn_graph": 4 * (N * 3 * 4 + N * 9 * 4),
+            "colsum": sum(N * 4 * h1 for _, h1, _ in conv) + N * 4 * (336 + 256),
+            "segment_pool_fwd": N * 256 * 4, "segment_pool_bwd": N * 256 * 4 * 2,
+        }
         dom = max(timers.items(), key=lambda kv: kv[1][1]) if timers else ("none", (1, 0.0))
         name, (launches, ms) = dom
         per_launch_ms = ms / max(launches, 1)
-        kernel_flops = {
-            # per launch, layers 2-4 shape (H1=336, H2=256); layer 1 (H1=128) is averaged in
-            "edgeconv_fwd": 2.0 * n_edges * 256 * (3 * 336 + 128) / 4,
-            "edgeconv_bwd": 2.0 * n_edges * 256 * (3 * 336 + 128) / 4,
-            "edgeconv_dw2": 2.0 * n_edges * 256 * (3 * 336 + 128) / 4,
-        }.get(name)
-        if kernel_flops is None:                       # a per-node GEMM dominates: price the whole path instead
-            kernel_flops = 3.0 * flops_fwd / max(launches / prof_steps, 1)
-        achieved = kernel_flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
+        lps = launches / prof_steps
+        if name in flops:
+            bound, unit = "mfma", "TFLOP/s"
+            achieved = flops[name] / lps / (per_launch_ms * 1e-3) / 1e12
+        else:
+            bound, unit, peak = "hbm", "GB/s", 8000.0
+            achieved = hbm_bytes.get(name, 0.0) / lps / (per_launch_ms * 1e-3) / 1e9
+        # measured HBM traffic per launch of that group (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # passes, FETCH_SIZE doubled as the gfx950 guide prescribes), recorded in profiles/r01_traffic.json
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            traffic = tj.get(name, {}).get("bytes_per_launch")
+        except Exception:
+            pass
         out = {
             "metric": "events/sec DynEdge fwd+bwd, IceCube-86 k=8",
             "value": total_events / dt, "unit": "events/s", "n_gpus": world, "steps": args.steps,
@@ -193,9 +218,10 @@ def main():
                                    "(~150/event, 7 features), k=8, fwd+bwd+Adam",
                        "events_per_gpu": args.events, "pulses_per_gpu": n_nodes, "edges_per_layer": n_edges,
                        "parallelism": f"dp{world} (event shards, one flat RCCL all-reduce)"},
-            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
-                         "launch_ms": per_launch_ms, "launches_per_step": launches / prof_steps},
+            "roofline": {"bound": bound, "kernel": name, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak, "traffic": traffic,
+                         "launch_ms": per_launch_ms, "launches_per_step": lps},
+            "group_tflops": {k: flops[k] / (timers[k][1] / prof_steps * 1e-3) / 1e12 for k in flops if k in timers},
             "path_roofline": {"algorithmic_tflop_per_step": 3.0 * flops_fwd * world / 1e12,
                               "achieved_tflops": 3.0 * flops_fwd * world * args.steps / dt / 1e12,
                               "frac_of_peak": 3.0 * flops_fwd * args.steps / dt / 1e12 / peak},
