@@ -35,8 +35,8 @@ SIGNATURES = {
     "gn_graph_globals": (I32, [P, I64, I32, P, I32, P, P, I32, P, P, P]),
     "gn_concat_globals": (I32, [P, I64, I32, P, I32, P, I32, P, I32, P]),
     "gn_linear_fwd": (I32, [I32, I32, P, P, P, P, I32, P, I32, I32, I32, P, P, I64, I32, I32, P, I64, I32, P]),
-    "gn_linear_wgrad_splits": (I32, [I32, I32]),
-    "gn_linear_wgrad": (I32, [I32, P, I64, I32, I32, P, P, P, I32, P, P, I32, P]),
+    "gn_linear_wgrad_parts": (I32, [I32, I32, I32, I32, P]),
+    "gn_linear_wgrad": (I32, [I32, P, I64, I32, I32, P, P, P, I32, P, P, P, P, I32, P]),
     "gn_colsum_blocks": (I32, [I32]),
     "gn_colsum": (I32, [P, I64, I32, I32, P, P, I32, P]),
     "gn_reduce_slabs": (I32, [P, I32, I64, P, I32, P]),

@@ -109,14 +109,18 @@ int gn_linear_fwd(int32_t mode, int32_t nseg, const float* const* a_ptr, const i
     if (r == hipErrorInvalidValue) return bad("gn_linear_fwd", "segment widths/pitches must be multiples of 4, kpad multiples of 32 summing to Kp");
     return fail(r, "gn_linear_fwd");
 }
-int32_t gn_linear_wgrad_splits(int32_t M, int32_t tiles) { return gn::gemm_tn_splits_for(M, tiles); }
+int32_t gn_linear_wgrad_parts(int32_t mode, int32_t M, int32_t N1, int32_t nseg, const int32_t* x_width) {
+    if (nseg < 1 || nseg > gn::MAXSEG || !x_width) return -1;
+    return gn::gemm_tn_parts(mode, M, N1, x_width, nseg);
+}
 int gn_linear_wgrad(int32_t mode, const float* dY, int64_t lddy, int32_t N1, int32_t nseg, const float* const* x_ptr,
-                    const int64_t* x_ld, const int32_t* x_width, int32_t M, float* slab, float* dW, int32_t accum,
-                    void* stream) {
+                    const int64_t* x_ld, const int32_t* x_width, int32_t M, float* slab, float* db_part, float* dW,
+                    float* db, int32_t accum, void* stream) {
     gn::Segs x;
     if (!make_segs(x, nseg, x_ptr, x_ld, x_width, nullptr)) return bad("gn_linear_wgrad", "bad X segments");
     if (reinterpret_cast<uintptr_t>(dY) & 15) return bad("gn_linear_wgrad", "dY must be 16-byte aligned");
-    hipError_t r = gn::launch_gemm_tn(mode, dY, lddy, N1, x, M, slab, dW, accum, S(stream));
+    if (db && !db_part) return bad("gn_linear_wgrad", "db needs db_part scratch");
+    hipError_t r = gn::launch_gemm_tn(mode, dY, lddy, N1, x, M, slab, db_part, dW, db, accum, S(stream));
     if (r == hipErrorInvalidValue) return bad("gn_linear_wgrad", "widths/pitches/N1 must be multiples of 4");
     return fail(r, "gn_linear_wgrad");
 }

@@ -233,6 +233,170 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 weight-gradient kernel, persistent over contraction rows (same structure as edge_dw2_v2):
+//   workgroup = (256-wide n1 tile, 128-wide k tile of ONE segment, row range `part`), 8 waves;
+//   wave w owns n1 block w (32 columns of dY) x 4 k blocks -> stationary 4(+1) x 32x32 accumulators;
+//   dY and X rows are converted to bf16 into double-buffered row-major LDS tiles [64][..] while the
+//   MFMAs of the previous tile run; BOTH operands contract over rows, so both fragments come from
+//   ds_read_b64_tr_b16 (hardware transpose) - no transposed 2-byte LDS writes;
+//   the k tile 0 workgroups also carry a constant-ones block: its accumulator is colsum(dY) = the
+//   bias gradient, for free (no separate pass over dY).
+// HBM-bound (fp32 inputs): algorithmic bytes = M*(N1 + K)*4.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pk_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
+__host__ __device__ constexpr int tr_pitch_g(int row_bytes) { return row_bytes + ((64 - row_bytes % 256) + 256) % 256; }
+
+constexpr int TN2_ROWS = 64, TN2_N1 = 256, TN2_K = 128;
+__global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
+    const float* __restrict__ dY, long long lddy, int N1, Segs x, int M, int nparts,
+    float* __restrict__ slab, float* __restrict__ db_part, int Ktot, int n1_tiles, int k_tiles)
+{
+    constexpr int YP = tr_pitch_g(TN2_N1 * 2);      // 576
+    constexpr int XP = tr_pitch_g(TN2_K * 2);       // 320
+    __shared__ __attribute__((aligned(16))) unsigned char Ys[2][TN2_ROWS * YP];
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[2][TN2_ROWS * XP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // blockIdx.x -> (part, k tile, n1 tile)
+    const int t1 = (int)blockIdx.x % n1_tiles;
+    int tk = ((int)blockIdx.x / n1_tiles) % k_tiles;
+    const int part = (int)blockIdx.x / (n1_tiles * k_tiles);
+    int kcol0 = 0, kout0 = 0, xw = 0;
+    const float* xp = nullptr;
+    long long ldx = 0;
+    bool found = false, first_k = (tk == 0);
+#pragma unroll
+    for (int s = 0; s < MAXSEG; ++s) {
+        if (s < x.nseg && !found) {
+            const int nt = (x.width[s] + TN2_K - 1) / TN2_K;
+            if (tk < nt) { kcol0 = tk * TN2_K; xp = x.p[s]; ldx = x.ld[s]; xw = x.width[s]; found = true; }
+            else { tk -= nt; kout0 += x.width[s]; }
+        }
+    }
+    if (!found) return;
+    const int n1_0 = t1 * TN2_N1;
+    const int ntile = (M + TN2_ROWS - 1) / TN2_ROWS;
+    const int per = (ntile + nparts - 1) / nparts;
+    int tile = part * per;
+    const int tile_end = min(ntile, tile + per);
+
+    f32x16 acc[4], accb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) zero_acc(acc[i]);
+    zero_acc(accb);
+
+    // staging: 8 threads per row; thread handles 16-byte bf16 chunks (tid&7)+8j (8 columns each)
+    const int srow = tid >> 3, sc = tid & 7;
+    f32x4 yr[4][2], xr[2][2];
+#define GN_TN2_LOAD(t_)                                                                              \
+    {                                                                                                \
+        const int m__ = (t_) * TN2_ROWS + srow;                                                      \
+        const bool mok__ = (t_) < tile_end && m__ < M;                                               \
+        const long long ms__ = mok__ ? m__ : 0;                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
+            const int c__ = n1_0 + (sc + 8 * j) * 8;                                                 \
+            const float* p__ = dY + ms__ * lddy;                                                     \
+            const f32x4 a__ = *reinterpret_cast<const f32x4*>(p__ + (c__ < N1 ? c__ : 0));          \
+            const f32x4 b__ = *reinterpret_cast<const f32x4*>(p__ + (c__ + 4 < N1 ? c__ + 4 : 0));  \
+            const f32x4 z__ = {0.f, 0.f, 0.f, 0.f};                                                  \
+            yr[j][0] = (mok__ && c__ < N1) ? a__ : z__;                                              \
+            yr[j][1] = (mok__ && c__ + 4 < N1) ? b__ : z__;                                          \
+        }                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+            const int c__ = kcol0 + (sc + 8 * j) * 8;                                                \
+            const float* p__ = xp + ms__ * ldx;                                                      \
+            const f32x4 a__ = *reinterpret_cast<const f32x4*>(p__ + (c__ < xw ? c__ : 0));           \
+            const f32x4 b__ = *reinterpret_cast<const f32x4*>(p__ + (c__ + 4 < xw ? c__ + 4 : 0));   \
+            const f32x4 z__ = {0.f, 0.f, 0.f, 0.f};                                                  \
+            xr[j][0] = (mok__ && c__ < xw) ? a__ : z__;                                              \
+            xr[j][1] = (mok__ && c__ + 4 < xw) ? b__ : z__;                                          \
+        }                                                                                            \
+    }
+#define GN_TN2_WRITE(buf_)                                                                           \
+    {                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
+            u32x4 w__;                                                                               \
+            w__[0] = pk_bf16(yr[j][0][0], yr[j][0][1]); w__[1] = pk_bf16(yr[j][0][2], yr[j][0][3]);  \
+            w__[2] = pk_bf16(yr[j][1][0], yr[j][1][1]); w__[3] = pk_bf16(yr[j][1][2], yr[j][1][3]);  \
+            *reinterpret_cast<u32x4*>(&Ys[buf_][srow * YP + (sc + 8 * j) * 16]) = w__;               \
+        }                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+            u32x4 w__;                                                                               \
+            w__[0] = pk_bf16(xr[j][0][0], xr[j][0][1]); w__[1] = pk_bf16(xr[j][0][2], xr[j][0][3]);  \
+            w__[2] = pk_bf16(xr[j][1][0], xr[j][1][1]); w__[3] = pk_bf16(xr[j][1][2], xr[j][1][3]);  \
+            *reinterpret_cast<u32x4*>(&Xs[buf_][srow * XP + (sc + 8 * j) * 16]) = w__;               \
+        }                                                                                            \
+    }
+    // out-of-range float4s are read from a clamped (valid) address and zeroed: branch-free staging
+
+    GN_TN2_LOAD(tile);
+    GN_TN2_WRITE(0);
+    __syncthreads();
+
+    const int g4 = lane >> 4, li = lane & 15;
+    const int tr_row = 8 * (g4 >> 1) + (li >> 2), tr_col = (16 * (g4 & 1) + 4 * (li & 3)) * 2;
+    const int ya_off = tr_row * YP + wave * 64 + tr_col;     // A: n1 block = wave
+    const int xb_off = tr_row * XP + tr_col;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    int buf = 0;
+    for (; tile < tile_end; ++tile, buf ^= 1) {
+        GN_TN2_LOAD(tile + 1);
+        typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned char* pa = &Ys[buf][ya_off + 16 * s * YP];
+            const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa));
+            const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * YP));
+            const s16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const unsigned char* pb = &Xs[buf][xb_off + 16 * s * XP + nb * 64];
+                const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb));
+                const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * XP));
+                const s16x8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[nb], 0, 0, 0);
+            }
+            if (first_k) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb, 0, 0, 0);
+        }
+        GN_TN2_WRITE(buf ^ 1);
+        __syncthreads();
+    }
+#undef GN_TN2_LOAD
+#undef GN_TN2_WRITE
+
+    float* out = slab + (long long)part * N1 * Ktot;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int kc = kcol0 + nb * 32 + r;
+        if (kc < xw) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int n1 = n1_0 + wave * 32 + acc_row(q, h);
+                if (n1 < N1) out[(long long)n1 * Ktot + kout0 + kc] = acc[nb][q];
+            }
+        }
+    }
+    if (first_k && db_part && r == 0) {             // every column of the ones block holds colsum(dY)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int n1 = n1_0 + wave * 32 + acc_row(q, h);
+            if (n1 < N1) db_part[(long long)part * N1 + n1] = accb[q];
+        }
+    }
+}
+
 // out[i] (+)= sum_s slab[s][i]   (fixed order -> deterministic)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int nslab, long long count,
                                                            float* __restrict__ out, int accum) {
@@ -292,6 +456,8 @@ namespace gn {
 
 static inline int cdiv_(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+int device_cus();
+
 template <typename T, int BN, int BKE, typename OutT>
 static hipError_t launch_gemm_nt_cfg(const Segs& a, int M, const void* Wp, int Kp, int Npad, int Nreal, const Epi& epi,
                                      void* C, long long ldc, hipStream_t st) {
@@ -313,7 +479,7 @@ static hipError_t launch_gemm_nt_t(const Segs& a, int M, const void* Wp, int Kp,
         // 256-wide N tile when that does not add padding (A is staged once for all of it)
         bool k64 = (Kp % 64) == 0;
         for (int s = 0; s < a.nseg; ++s) k64 = k64 && (a.kpad[s] % 64) == 0;
-        static const bool allow_wide = !(getenv("GN_GEMM_WIDE") && getenv("GN_GEMM_WIDE")[0] == '0');
+        static const bool allow_wide = getenv("GN_GEMM_WIDE") && getenv("GN_GEMM_WIDE")[0] == '1';   // measured slower
         static const bool allow_k64 = !(getenv("GN_GEMM_K64") && getenv("GN_GEMM_K64")[0] == '0');
         k64 = k64 && allow_k64;
         const bool wide = allow_wide && cdiv_(Nreal, 256) * 256 <= cdiv_(Nreal, 128) * 128 && cdiv_(Nreal, 256) * 256 <= Npad;
@@ -347,27 +513,60 @@ int gemm_tn_splits_for(int M, int tiles) {
     return s;
 }
 
-// dW[N1, Ktot] (+)= dY^T . [X_seg0 | X_seg1 | ...];  slab: >= splits*N1*Ktot floats
+hipError_t launch_colsum(const float* X, long long ld, int M, int C, float* part, float* out, int accum, hipStream_t st);
+int colsum_blocks(int M);
+int device_cus();
+// number of row-range parts (= slabs) the weight-gradient kernels write
+int gemm_tn_parts(int mode, int M, int N1, const int* widths, int nseg) {
+    if (mode == 1) {
+        int kt = 0;
+        for (int s = 0; s < nseg; ++s) kt += cdiv_(widths[s], TN2_K);
+        const int pops = cdiv_(N1, TN2_N1) * kt;
+        int parts = device_cus() / (pops > 0 ? pops : 1);
+        const int maxp = cdiv_(M > 0 ? M : 1, TN2_ROWS);
+        if (parts > maxp) parts = maxp;
+        return parts > 0 ? parts : 1;
+    }
+    int kt = 0;
+    for (int s = 0; s < nseg; ++s) kt += cdiv_(widths[s], 128);
+    return gemm_tn_splits_for(M, cdiv_(N1, 128) * kt);
+}
+
+// dW[N1, Ktot] (+)= dY^T . [X_seg0 | X_seg1 | ...];  db[N1] (+)= colsum(dY) when db != null.
+// slab: >= parts*N1*Ktot floats, db_part: >= parts*N1 floats (parts = gemm_tn_parts()).
 hipError_t launch_gemm_tn(int mode, const float* dY, long long lddy, int N1, const Segs& x, int M, float* slab,
-                          float* dW, int accum, hipStream_t st) {
-    int Ktot = 0, ktiles = 0;
+                          float* db_part, float* dW, float* db, int accum, hipStream_t st) {
+    int Ktot = 0, ktiles = 0, ktiles2 = 0;
     for (int s = 0; s < x.nseg; ++s) {
         if ((x.width[s] & 3) || (x.ld[s] & 3)) return hipErrorInvalidValue;
         Ktot += x.width[s];
         ktiles += cdiv_(x.width[s], 128);
+        ktiles2 += cdiv_(x.width[s], TN2_K);
     }
     if ((lddy & 3) || (N1 & 3)) return hipErrorInvalidValue;
+    const long long count = (long long)N1 * Ktot;
+    if (mode == 1) {
+        const int parts = gemm_tn_parts(mode, M, N1, x.width, x.nseg);
+        const int n1t = cdiv_(N1, TN2_N1);
+        hipLaunchKernelGGL(gemm_tn_v2_kernel, dim3(n1t * ktiles2 * parts), dim3(512), 0, st, dY, lddy, N1, x, M, parts,
+                           slab, db ? db_part : nullptr, Ktot, n1t, ktiles2);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(count, 256)), dim3(256), 0, st, slab, parts, count, dW, accum);
+        if (db)
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(N1, 256)), dim3(256), 0, st, db_part, parts, (long long)N1,
+                               db, accum);
+        return hipGetLastError();
+    }
     const int splits = gemm_tn_splits_for(M, cdiv_(N1, 128) * ktiles);
     int rps = cdiv_(M > 0 ? M : 1, splits);
     rps = cdiv_(rps, BK) * BK;
     const int n1t = cdiv_(N1, 128);
     dim3 grid(n1t * ktiles, splits);
-    if (mode == 0)
-        hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, st, dY, lddy, N1, x, M, rps, slab, Ktot, n1t);
-    else
-        hipLaunchKernelGGL((gemm_tn_kernel<__bf16>), grid, dim3(256), 0, st, dY, lddy, N1, x, M, rps, slab, Ktot, n1t);
-    const long long count = (long long)N1 * Ktot;
+    hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, st, dY, lddy, N1, x, M, rps, slab, Ktot, n1t);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(count, 256)), dim3(256), 0, st, slab, splits, count, dW, accum);
+    if (db) {                                          // f32 mode: separate column-sum pass
+        hipError_t e = launch_colsum(dY, lddy, M, N1, db_part, db, accum, st);
+        if (e != hipSuccess) return e;
+    }
     return hipGetLastError();
 }
 

@@ -24,9 +24,9 @@ hipError_t launch_ptr_to_batch(const int* ptr, int B, int* batch, hipStream_t st
 // gemm.hip
 hipError_t launch_gemm_nt(int mode, const Segs& a, int M, const void* Wp, int Kp, int Npad, int Nreal, const Epi& epi,
                           void* C, long long ldc, int out_lowp, hipStream_t st);
-int gemm_tn_splits_for(int M, int tiles);
+int gemm_tn_parts(int mode, int M, int N1, const int* widths, int nseg);
 hipError_t launch_gemm_tn(int mode, const float* dY, long long lddy, int N1, const Segs& x, int M, float* slab,
-                          float* dW, int accum, hipStream_t st);
+                          float* db_part, float* dW, float* db, int accum, hipStream_t st);
 int colsum_blocks(int M);
 hipError_t launch_colsum(const float* X, long long ld, int M, int C, float* part, float* out, int accum, hipStream_t st);
 hipError_t launch_reduce_slabs(const float* slab, int nslab, long long count, float* out, int accum, hipStream_t st);

@@ -174,9 +174,9 @@ class _DynEdgeFunction(torch.autograd.Function):
             W, b = post_p[t]
             Pt = int(W.shape[0])
             in_segs = xs if t == 0 else [ys[t - 1]]
-            grads[4 * nconv + 2 * t] = _unpad_cols(ops.linear_wgrad(mode, dZ, Pt, _ksegs(in_segs)),
-                                                   [w for _, w in in_segs])
-            grads[4 * nconv + 2 * t + 1] = ops.colsum(dZ, Pt)
+            dWt, dbt = ops.linear_wgrad(mode, dZ, Pt, _ksegs(in_segs), with_bias=True)
+            grads[4 * nconv + 2 * t] = _unpad_cols(dWt, [w for _, w in in_segs])
+            grads[4 * nconv + 2 * t + 1] = dbt
             if t > 0:
                 yprev, Pprev = ys[t - 1]
                 dZ = ops.linear_fwd(mode, [(dZ, Pt)], ops.pack_weight(W.t(), [Pt], dt, ku), Pprev, gate=yprev)
@@ -202,10 +202,11 @@ class _DynEdgeFunction(torch.autograd.Function):
             ops.edgeconv_bwd(mode, g, PQ, H1p, H2, g_out, mask, ops.pack_weight(W2.t(), [H2], dt), dpre,
                              dPQ[:, :H1p])
             ops.edgeconv_dq_gather(mode, g, dpre, H1p, dPQ[:, H1p:])
-            dWpq = ops.linear_wgrad(mode, dPQ, 2 * H1p, [(xin, _kw(Fin))])[:, :Fin]
+            dWpq, dbpq = ops.linear_wgrad(mode, dPQ, 2 * H1p, [(xin, _kw(Fin))], with_bias=True)
+            dWpq = dWpq[:, :Fin]
             dWp, dWq = dWpq[:H1], dWpq[H1p:H1p + H1]
             grads[4 * l] = torch.cat([dWp, dWq - dWp], dim=1)
-            grads[4 * l + 1] = ops.colsum(dPQ, H1)
+            grads[4 * l + 1] = dbpq[:H1]
             grads[4 * l + 2] = dW2
             grads[4 * l + 3] = db2
             if l > 0:

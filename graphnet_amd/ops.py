@@ -272,23 +272,28 @@ def linear_fwd(mode: int, segs: Sequence[Seg], Wp: Tensor, n_real: int, bias: Op
 
 
 def linear_wgrad(mode: int, dY: Tensor, n1: int, segs: Sequence[Seg], out: Optional[Tensor] = None,
-                 accum: bool = False) -> Tensor:
-    """``dW[n1, sum widths] (+)= dY[:, :n1]^T @ cat(segs)`` (deterministic split reduction)."""
+                 accum: bool = False, with_bias: bool = False):
+    """``dW[n1, sum widths] (+)= dY[:, :n1]^T @ cat(segs)`` (deterministic split reduction).
+    ``with_bias``: also return ``db[n1] = colsum(dY)`` from the same pass -> ``(dW, db)``."""
     _need(dY, torch.float32, "dY")
     n, ptrs, lds, widths, _ = _seg_arrays(segs, False)
     M = int(dY.shape[0])
     ktot = sum(int(s[1]) for s in segs)
     L = _lib.lib()
-    tiles = ((n1 + 127) // 128) * sum((int(s[1]) + 127) // 128 for s in segs)
-    splits = int(L.gn_linear_wgrad_splits(M, tiles))
-    slab = torch.empty(splits * n1 * ktot, dtype=torch.float32, device=dY.device)
+    parts = int(L.gn_linear_wgrad_parts(mode, M, n1, n, ctypes.cast(widths, ctypes.c_void_p)))
+    dev = dY.device
+    slab = torch.empty(parts * n1 * ktot, dtype=torch.float32, device=dev)
+    db = dbp = None
+    if with_bias:
+        dbp = torch.empty(max(parts, int(L.gn_colsum_blocks(M))) * n1, dtype=torch.float32, device=dev)
+        db = torch.empty(n1, dtype=torch.float32, device=dev)
     if out is None:
-        out = torch.empty((n1, ktot), dtype=torch.float32, device=dY.device)
+        out = torch.empty((n1, ktot), dtype=torch.float32, device=dev)
     with _timed("linear_wgrad"):
         _lib.check(L.gn_linear_wgrad(mode, _p(dY), _rows(dY, "dY"), n1, n, ctypes.cast(ptrs, ctypes.c_void_p),
                                      ctypes.cast(lds, ctypes.c_void_p), ctypes.cast(widths, ctypes.c_void_p), M,
-                                     _p(slab), _p(out), int(accum), _st()))
-    return out
+                                     _p(slab), _p(dbp), _p(out), _p(db), int(accum), _st()))
+    return (out, db) if with_bias else out
 
 
 def colsum(X: Tensor, C: int, out: Optional[Tensor] = None, accum: bool = False) -> Tensor:

@@ -86,12 +86,14 @@ int gn_linear_fwd(int32_t mode, int32_t nseg, const float* const* a_ptr, const i
                   const float* bias, const float* gate, int64_t ldgate, int32_t relu, int32_t accum,
                   void* C, int64_t ldc, int32_t out_lowp, void* stream);
 
-/* dW[N1, sum width_s] (+)= dY[M,N1]^T . [X_0 | X_1 | ...]; slab: >= gn_linear_wgrad_splits(M, tiles)*N1*Ktot
- * floats with tiles = ceil(N1/128) * sum_s ceil(width_s/128) */
-int32_t gn_linear_wgrad_splits(int32_t M, int32_t tiles);
+/* dW[N1, sum width_s] (+)= dY[M,N1]^T . [X_0 | X_1 | ...] and, if db != NULL, db[N1] (+)= colsum(dY)
+ * (the bias gradient, produced by the same pass in bf16 mode).  Scratch: slab >= parts*N1*Ktot floats,
+ * db_part >= max(parts, gn_colsum_blocks(M))*N1 floats, parts = gn_linear_wgrad_parts().
+ * x_width: HOST int[nseg]. */
+int32_t gn_linear_wgrad_parts(int32_t mode, int32_t M, int32_t N1, int32_t nseg, const int32_t* x_width_host);
 int gn_linear_wgrad(int32_t mode, const float* dY, int64_t lddy, int32_t N1, int32_t nseg,
                     const float* const* x_ptr, const int64_t* x_ld, const int32_t* x_width, int32_t M,
-                    float* slab, float* dW, int32_t accum, void* stream);
+                    float* slab, float* db_part, float* dW, float* db, int32_t accum, void* stream);
 
 /* out[C] (+)= column sums of X[M, C]; part: >= gn_colsum_blocks(M)*C floats */
 int32_t gn_colsum_blocks(int32_t M);

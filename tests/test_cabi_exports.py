@@ -36,7 +36,9 @@ def test_host_only_entry_points(lib):
     assert lib.gn_abi_version() == 1
     assert lib.gn_edge_slots(8) == 8 and lib.gn_edge_slots(9) == 16 and lib.gn_edge_slots(17) == 32
     assert lib.gn_scan_tmp_ints(150000) >= 74
-    assert lib.gn_linear_wgrad_splits(150000, 27) >= 1 and lib.gn_colsum_blocks(1000) == 4
+    import ctypes
+    w = (ctypes.c_int32 * 2)(32, 256)
+    assert lib.gn_linear_wgrad_parts(1, 150000, 336, 2, ctypes.cast(w, ctypes.c_void_p)) >= 1 and lib.gn_colsum_blocks(1000) == 4
     assert lib.gn_edgeconv_dw2_slabs(0, 150_000, 8, 352, 256) >= 300
     assert lib.gn_edgeconv_saved_bytes(1000, 8, 352, 256) >= 1000 * 256 + 8000 * 44
 

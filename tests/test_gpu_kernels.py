@@ -193,10 +193,15 @@ def test_linear_wgrad_and_colsum(name, mode, tol):
     xa, xb = torch.randn(M, 32), torch.randn(M, 256)
     xa[:, 19:] = 0
     ref = dY.t() @ torch.cat([xa, xb], 1)
-    dW = ops.linear_wgrad(mode, dY.to(DEV), 336, [(xa.to(DEV), 32), (xb.to(DEV), 256)])
+    dW, db = ops.linear_wgrad(mode, dY.to(DEV), 336, [(xa.to(DEV), 32), (xb.to(DEV), 256)], with_bias=True)
     assert rel_err(dW, ref) < tol
+    assert rel_err(db, dY.sum(0)) < (1e-5 if mode == 0 else 1e-2)       # bf16 mode: dY rounded to bf16 in the ones-MFMA
     dW2 = ops.linear_wgrad(mode, dY.to(DEV), 336, [(xa.to(DEV), 32), (xb.to(DEV), 256)])
     assert torch.equal(dW, dW2), "split reduction must be bitwise reproducible"
+    # wide / ragged shapes: N1 not a multiple of the tile, several k tiles, M not a multiple of 64
+    dY3, x3 = torch.randn(1237, 708), torch.randn(1237, 260)
+    dW3, db3 = ops.linear_wgrad(mode, dY3.to(DEV), 708, [(x3.to(DEV), 260)], with_bias=True)
+    assert rel_err(dW3, dY3.t() @ x3) < tol and rel_err(db3, dY3.sum(0)) < (1e-5 if mode == 0 else 1e-2)
     cs = ops.colsum(dY.to(DEV), 336)
     assert rel_err(cs, dY.sum(0)) < 1e-5
 
