@@ -150,6 +150,11 @@ def main():
     # per-kernel durations: HIP events on the launch stream around every C-ABI op.  A graph replay has
     # no per-kernel events, so the same kernels are timed in a few eager steps right after the timed
     # region (same process, same buffers); rocprofv3 --kernel-trace of this command must agree.
+    fence()
+    th = time.perf_counter()
+    eager_step()                                              # host time to ENQUEUE one step (no sync)
+    host_issue_ms = 1e3 * (time.perf_counter() - th)
+    fence()
     ops.enable_timers(True)
     for _ in range(max(1, args.profile_steps)):
         eager_step()
@@ -226,7 +231,7 @@ def main():
                               "achieved_tflops": 3.0 * flops_fwd * world * args.steps / dt / 1e12,
                               "frac_of_peak": 3.0 * flops_fwd * args.steps / dt / 1e12 / peak},
             "phase_ms_per_step": {k: v[1] / prof_steps for k, v in sorted(timers.items(), key=lambda kv: -kv[1][1])},
-            "launch": launch,
+            "launch": launch, "host_issue_ms": host_issue_ms,
             "final_loss": float(loss.detach()),
         }
         if world == 1 and not args.no_cpu_baseline:

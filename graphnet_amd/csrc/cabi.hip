@@ -43,12 +43,18 @@ extern "C" {
 const char* gn_last_error(void) { return g_err; }
 int gn_abi_version(void) { return 1; }
 
-int gn_knn_graph(const float* x, int64_t ldx, const int32_t* cols_host, int32_t D, const int32_t* batch,
-                 const int32_t* ptr, int32_t N, int32_t k, int32_t strict, int32_t* nbr, int32_t* ovf, void* stream) {
-    if (N < 0 || k < 1 || k > 32 || D < 1 || D > 8 || !cols_host) return bad("gn_knn_graph", "need 1<=k<=32, 1<=D<=8");
+int gn_knn_plan(const int32_t* ptr, int32_t B, int32_t* tile_ptr, void* stream) {
+    if (B < 0 || !ptr || !tile_ptr) return bad("gn_knn_plan", "need ptr[B+1] and tile_ptr[B+1]");
+    return fail(gn::launch_knn_plan(ptr, B, tile_ptr, S(stream)), "gn_knn_plan");
+}
+int gn_knn_graph(const float* x, int64_t ldx, const int32_t* cols_host, int32_t D, const int32_t* ptr,
+                 const int32_t* tile_ptr, int32_t B, int32_t N, int32_t k, int32_t strict, int32_t* nbr, int32_t* ovf,
+                 void* stream) {
+    if (N < 0 || B < 0 || k < 1 || k > 32 || D < 1 || D > 8 || !cols_host) return bad("gn_knn_graph", "need 1<=k<=32, 1<=D<=8");
+    if (N > 0 && B > 0 && !tile_ptr) return bad("gn_knn_graph", "needs the tile plan of gn_knn_plan");
     if (!strict && !ovf) return bad("gn_knn_graph", "compat mode needs ovf[N]");
     for (int d = 0; d < D; ++d) if (cols_host[d] < 0 || cols_host[d] >= ldx) return bad("gn_knn_graph", "column out of range");
-    return fail(gn::launch_knn(x, ldx, cols_host, D, batch, ptr, N, k, strict, nbr, ovf, S(stream)), "gn_knn_graph");
+    return fail(gn::launch_knn(x, ldx, cols_host, D, ptr, tile_ptr, B, N, k, strict, nbr, ovf, S(stream)), "gn_knn_graph");
 }
 
 int64_t gn_scan_tmp_ints(int64_t n) { return (n + 2047) / 2048 + 1; }

@@ -17,102 +17,138 @@
 namespace gn {
 
 constexpr int KNN_DMAX = 8;
-constexpr int KNN_CH = 1024;   // candidates per LDS chunk
-constexpr int KNN_BLOCK = 256;
+constexpr int KNN_CH = 256;    // candidates per LDS chunk (8 KB: 20 single-wave workgroups per CU)
+constexpr int KNN_TILE = 64;   // queries per workgroup = one wave
 
 struct KnnCols { int c[KNN_DMAX]; };
 
+// Query tiles are aligned to events: tile t of event e holds queries ptr[e]+64t .. ptr[e]+64t+63, so a
+// wave only ever scans candidates of ITS OWN event (a tile spanning events would scan their union).
+// tile_ptr[e] = sum_{e'<e} ceil(n_e'/64) is built once per batch by knn_plan_kernel; a workgroup (one
+// wave) finds its event by binary search over tile_ptr (wave-uniform scalar loads).
+__global__ __launch_bounds__(256) void knn_plan_kernel(const int* __restrict__ ptr, int B, int* __restrict__ tile_ptr) {
+    __shared__ int lds[256 / 64];
+    int carry = 0;
+    for (int e0 = 0; e0 < B; e0 += 256) {
+        const int e = e0 + (int)threadIdx.x;
+        const int v = e < B ? (max(ptr[e + 1] - ptr[e], 0) + KNN_TILE - 1) / KNN_TILE : 0;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) lds[w] = incl;
+        __syncthreads();
+        int base = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int sv = lds[i]; if (i < w) base += sv; tot += sv; }
+        __syncthreads();
+        if (e < B) tile_ptr[e] = carry + base + incl - v;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) tile_ptr[B] = carry;
+}
+
 template <int KMAX>
-__global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(
+__global__ __launch_bounds__(KNN_TILE) void knn_kernel(
     const float* __restrict__ x, long long ldx, KnnCols cols, int D,
-    const int* __restrict__ batch, const int* __restrict__ ptr, int N,
-    int k, int strict, int* __restrict__ nbr, int* __restrict__ ovf)
+    const int* __restrict__ ptr, const int* __restrict__ tile_ptr, int B, int N, int k, int strict,
+    int* __restrict__ nbr, int* __restrict__ ovf)
 {
 #pragma clang fp contract(off)
-    __shared__ float cand[KNN_DMAX][KNN_CH];
-    const int q = blockIdx.x * KNN_BLOCK + threadIdx.x;
-    const bool active = q < N;
-    const int q0 = blockIdx.x * KNN_BLOCK;
-    const int qlast = min(q0 + KNN_BLOCK, N) - 1;
-    const int blo = ptr[batch[q0]];
-    const int bhi = ptr[batch[qlast] + 1];
+    __shared__ __attribute__((aligned(16))) float cand[KNN_DMAX][KNN_CH];
+    const int w = blockIdx.x;
+    if (w >= tile_ptr[B]) return;
+    int elo = 0, ehi = B;                       // largest e with tile_ptr[e] <= w  (empty events share a value)
+    while (ehi - elo > 1) {
+        const int mid = (elo + ehi) >> 1;
+        if (tile_ptr[mid] <= w) elo = mid; else ehi = mid;
+    }
+    const int ev = elo;
+    const int hi = min(ptr[ev + 1], N), lo = min(max(ptr[ev], 0), hi);   // never index past x[N]
+    const int kk = strict ? k : k + 1;
+    const int q = lo + (w - tile_ptr[ev]) * KNN_TILE + (int)threadIdx.x;
+    const bool active = q < hi;
+    const float INF = __builtin_inff();
 
-    int mylo = 0, myhi = 0;
     float qc[KNN_DMAX];
 #pragma unroll
-    for (int d = 0; d < KNN_DMAX; ++d) qc[d] = 0.0f;
-    if (active) {
-        const int b = batch[q];
-        mylo = ptr[b];
-        myhi = ptr[b + 1];
-#pragma unroll
-        for (int d = 0; d < KNN_DMAX; ++d)
-            if (d < D) qc[d] = x[(long long)q * ldx + cols.c[d]];
-    }
-    // wave-uniform scan bounds
-    int wlo = active ? mylo : 0x7fffffff, whi = active ? myhi : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        wlo = min(wlo, __shfl_xor(wlo, o));
-        whi = max(whi, __shfl_xor(whi, o));
-    }
-
+    for (int d = 0; d < KNN_DMAX; ++d) qc[d] = (active && d < D) ? x[(long long)q * ldx + cols.c[d]] : 0.0f;
     float bd[KMAX];
     int bj[KMAX];
 #pragma unroll
     for (int e = 0; e < KMAX; ++e) { bd[e] = 1e10f; bj[e] = -1; }
-    const int kk = strict ? k : k + 1;
 
-    for (int c0 = blo; c0 < bhi; c0 += KNN_CH) {
-        const int cn = min(KNN_CH, bhi - c0);
+    for (int c0 = lo; c0 < hi; c0 += KNN_CH) {
+        const int cn = min(KNN_CH, hi - c0);
+        const int cn4 = (cn + 3) & ~3;
         __syncthreads();
-        for (int t = threadIdx.x; t < cn; t += KNN_BLOCK) {
-            const float* row = x + (long long)(c0 + t) * ldx;
+        for (int t = threadIdx.x; t < cn4; t += KNN_TILE) {
+            const float* row = x + (long long)(c0 + min(t, cn - 1)) * ldx;
 #pragma unroll
             for (int d = 0; d < KNN_DMAX; ++d)
-                if (d < D) cand[d][t] = row[cols.c[d]];
+                if (d < D) cand[d][t] = t < cn ? row[cols.c[d]] : 3.0e38f;      // pad: d2 = inf, never taken
         }
         __syncthreads();
-        const int jb = max(c0, wlo), je = min(c0 + cn, whi);
-        for (int j = jb; j < je; ++j) {
-            float d2 = 0.0f;
+        for (int jl = 0; jl < cn4; jl += 4) {
+            float cd[KNN_DMAX][4];
 #pragma unroll
             for (int d = 0; d < KNN_DMAX; ++d) {
                 if (d < D) {
-                    const float diff = cand[d][j - c0] - qc[d];
-                    const float sq = diff * diff;
-                    d2 = d2 + sq;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&cand[d][jl]);
+                    cd[d][0] = v[0]; cd[d][1] = v[1]; cd[d][2] = v[2]; cd[d][3] = v[3];
                 }
             }
-            const bool ok = active && j >= mylo && j < myhi && !(strict && j == q);
-            // kk-th best is the admission threshold; list beyond kk is never consulted
-            if (ok && bd[KMAX - 1] > d2) {
 #pragma unroll
-                for (int t = KMAX - 1; t > 0; --t) {
-                    const float prev = bd[t - 1];
-                    if (prev > d2) { bd[t] = prev; bj[t] = bj[t - 1]; }
-                    else if (bd[t] > d2) { bd[t] = d2; bj[t] = j; }
+            for (int u = 0; u < 4; ++u) {
+                const int j = c0 + jl + u;
+                float d2 = 0.0f;
+#pragma unroll
+                for (int d = 0; d < KNN_DMAX; ++d) {
+                    if (d < D) {
+                        const float diff = cd[d][u] - qc[d];
+                        const float sq = diff * diff;
+                        d2 = d2 + sq;
+                    }
                 }
-                if (bd[0] > d2) { bd[0] = d2; bj[0] = j; }
+                // inactive lanes, the query itself (strict) and NaN/inf distances never enter the list
+                const bool ok = active && !(strict && j == q) && d2 < INF;
+                d2 = ok ? d2 : INF;
+                if (d2 < bd[KMAX - 1]) {
+                    // sorted insert after equal keys: new[t] = med3(old[t-1], d2, old[t]); index follows
+                    bool ct = true;                                   // d2 < old[t]
+#pragma unroll
+                    for (int t = KMAX - 1; t > 0; --t) {
+                        const bool cp = d2 < bd[t - 1];               // d2 < old[t-1]
+                        bj[t] = cp ? bj[t - 1] : (ct ? j : bj[t]);
+                        bd[t] = __builtin_amdgcn_fmed3f(bd[t - 1], d2, bd[t]);
+                        ct = cp;
+                    }
+                    bj[0] = ct ? j : bj[0];
+                    bd[0] = ct ? d2 : bd[0];
+                }
             }
         }
     }
-    if (!active) return;
-    int c = 0;
-    int extra = -1;
+    if (active) {
+        int c = 0;
+        int extra = -1;
 #pragma unroll
-    for (int e = 0; e < KMAX; ++e) {
-        if (e < kk) {
-            const int j = bj[e];
-            if (j >= 0 && j != q) {
-                if (c < k) nbr[(long long)q * k + c] = j;
-                else extra = j;
-                ++c;
+        for (int e = 0; e < KMAX; ++e) {
+            if (e < kk) {
+                const int j = bj[e];
+                if (j >= 0 && j != q) {
+                    if (c < k) nbr[(long long)q * k + c] = j;
+                    else extra = j;
+                    ++c;
+                }
             }
         }
+        for (; c < k; ++c) nbr[(long long)q * k + c] = -1;
+        if (ovf) ovf[q] = extra;
     }
-    for (; c < k; ++c) nbr[(long long)q * k + c] = -1;
-    if (ovf) ovf[q] = extra;
 }
 
 // ---------------------------------------------------------------- exclusive scan (int32)
@@ -347,16 +383,23 @@ namespace gn {
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-hipError_t launch_knn(const float* x, long long ldx, const int* cols, int D, const int* batch, const int* ptr,
-                      int N, int k, int strict, int* nbr, int* ovf, hipStream_t st) {
-    if (N == 0) return hipSuccess;
+hipError_t launch_knn_plan(const int* ptr, int B, int* tile_ptr, hipStream_t st) {
+    hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, tile_ptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn(const float* x, long long ldx, const int* cols, int D, const int* ptr, const int* tile_ptr,
+                      int B, int N, int k, int strict, int* nbr, int* ovf, hipStream_t st) {
+    if (N == 0 || B == 0) return hipSuccess;
     KnnCols kc;
     for (int d = 0; d < KNN_DMAX; ++d) kc.c[d] = d < D ? cols[d] : 0;
     const int kk = strict ? k : k + 1;
-    dim3 grid(cdiv(N, KNN_BLOCK)), block(KNN_BLOCK);
-    if (kk <= 9) hipLaunchKernelGGL(knn_kernel<9>, grid, block, 0, st, x, ldx, kc, D, batch, ptr, N, k, strict, nbr, ovf);
-    else if (kk <= 17) hipLaunchKernelGGL(knn_kernel<17>, grid, block, 0, st, x, ldx, kc, D, batch, ptr, N, k, strict, nbr, ovf);
-    else hipLaunchKernelGGL(knn_kernel<33>, grid, block, 0, st, x, ldx, kc, D, batch, ptr, N, k, strict, nbr, ovf);
+    // upper bound of sum ceil(n_e/64) known without reading ptr on the host; surplus workgroups exit at once
+    const long long tiles = (long long)N / KNN_TILE + B;
+    dim3 grid((unsigned)tiles), block(KNN_TILE);
+    if (kk <= 9) hipLaunchKernelGGL(knn_kernel<9>, grid, block, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, k, strict, nbr, ovf);
+    else if (kk <= 17) hipLaunchKernelGGL(knn_kernel<17>, grid, block, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, k, strict, nbr, ovf);
+    else hipLaunchKernelGGL(knn_kernel<33>, grid, block, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, k, strict, nbr, ovf);
     return hipGetLastError();
 }
 

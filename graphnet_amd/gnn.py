@@ -108,6 +108,7 @@ class _DynEdgeFunction(torch.autograd.Function):
         x0 = ops.concat_globals(x, gv if G else None, batch, ops.round_up(F0, 32))
         xs: List[Tuple[Tensor, int]] = [(x0, F0)]
         graphs, PQs, masks = [], [], []
+        plan = None
         for l, (W1, b1, W2, b2) in enumerate(conv_p):
             xin, Fin = xs[-1]
             H1, H2 = int(W1.shape[0]), int(W2.shape[0])
@@ -124,8 +125,10 @@ class _DynEdgeFunction(torch.autograd.Function):
             graphs.append(g); PQs.append(PQ); masks.append(mask)
             xs.append((out, H2))
             if l + 1 < nconv:
+                if plan is None:
+                    plan = ops.knn_plan(ptr)                  # query-tile plan: once per batch, all layers
                 g = ops.knn_graph(out, _subset_cols(cfg["features_subset"], H2), batch, ptr, cfg["k"],
-                                  strict=cfg["strict"])
+                                  strict=cfg["strict"], plan=plan)
         ys: List[Tuple[Tensor, int]] = []
         segs = xs
         for (W, b) in post_p:

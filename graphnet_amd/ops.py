@@ -157,9 +157,19 @@ def _finish_table(nbr: Tensor, ovf: Optional[Tensor], K: int) -> NeighbourTable:
     return NeighbourTable(nbr, ovf, oc, os_, cnt, K)
 
 
+def knn_plan(ptr: Tensor) -> Tensor:
+    """Query-tile plan of a batch (``gn_knn_plan``): build once, pass to every ``knn_graph`` of the batch."""
+    _need(ptr, torch.int32, "ptr")
+    plan = torch.empty(int(ptr.shape[0]), dtype=torch.int32, device=ptr.device)
+    _lib.check(_lib.lib().gn_knn_plan(_p(ptr), int(ptr.shape[0]) - 1, _p(plan), _st()))
+    return plan
+
+
 def knn_graph(x: Tensor, cols: Sequence[int], batch: Tensor, ptr: Tensor, k: int,
-              strict: bool = False) -> NeighbourTable:
+              strict: bool = False, plan: Optional[Tensor] = None) -> NeighbourTable:
     """Batched brute-force k-NN on ``x[:, cols]`` (fp32) inside each event."""
+    if plan is None:
+        plan = knn_plan(ptr)
     _need(x, torch.float32, "x"); _need(batch, torch.int32, "batch"); _need(ptr, torch.int32, "ptr")
     N = int(x.shape[0])
     ld = _rows(x, "x")
@@ -167,8 +177,8 @@ def knn_graph(x: Tensor, cols: Sequence[int], batch: Tensor, ptr: Tensor, k: int
     ovf = None if strict else torch.empty(max(N, 1), dtype=torch.int32, device=x.device)
     c = (ctypes.c_int32 * len(cols))(*[int(v) for v in cols])
     with _timed("knn_graph"):
-        _lib.check(_lib.lib().gn_knn_graph(_p(x), ld, ctypes.cast(c, ctypes.c_void_p), len(cols), _p(batch), _p(ptr),
-                                           N, k, 1 if strict else 0, _p(nbr), _p(ovf), _st()))
+        _lib.check(_lib.lib().gn_knn_graph(_p(x), ld, ctypes.cast(c, ctypes.c_void_p), len(cols), _p(ptr),
+                                           _p(plan), int(ptr.shape[0]) - 1, N, k, 1 if strict else 0, _p(nbr), _p(ovf), _st()))
     return _finish_table(nbr, None if strict else ovf[:N] if N else ovf, k)
 
 

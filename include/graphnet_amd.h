@@ -39,8 +39,11 @@ int gn_abi_version(void);
  * cols: HOST int[D] (D <= 8).  strict = 0: k+1-with-self then mask (degree k or k+1, the extra
  * neighbour goes to ovf[N], -1 if none); strict = 1: self excluded, ovf may be NULL. */
 int gn_knn_graph(const float* x, int64_t ldx, const int32_t* cols_host, int32_t D,
-                 const int32_t* batch, const int32_t* ptr, int32_t N, int32_t k, int32_t strict,
+                 const int32_t* ptr, const int32_t* tile_ptr, int32_t B, int32_t N, int32_t k, int32_t strict,
                  int32_t* nbr, int32_t* ovf, void* stream);
+/* Query-tile plan of a batch (once per batch, shared by every k-NN layer): tile_ptr[e] = number of
+ * 64-query tiles of the events before e, tile_ptr[B] = their total (<= N/64 + B).  Device int32[B+1]. */
+int gn_knn_plan(const int32_t* ptr, int32_t B, int32_t* tile_ptr, void* stream);
 
 /* exclusive scan; tmp: >= gn_scan_tmp_ints(n) ints; total (optional) receives the sum */
 int64_t gn_scan_tmp_ints(int64_t n);
