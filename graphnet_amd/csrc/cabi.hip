@@ -174,7 +174,7 @@ int gn_edgeconv_bwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre,
 int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int32_t* rev_ptr, const int32_t* rev_rows,
                           int32_t N, float* dQ, int64_t ldq, void* stream) {
     hipError_t r = gn::launch_dq_gather(mode, dpre, H1p, rev_ptr, rev_rows, N, dQ, ldq, S(stream));
-    if (r == hipErrorInvalidValue) return bad("gn_edgeconv_dq_gather", "need H1p <= 512, H1p%4==0, ldq%4==0");
+    if (r == hipErrorInvalidValue) return bad("gn_edgeconv_dq_gather", "need H1p <= 512, H1p%8==0, ldq%4==0");
     return fail(r, "gn_edgeconv_dq_gather");
 }
 

@@ -444,6 +444,30 @@ __global__ __launch_bounds__(256) void edge_dw2_kernel(
 
 // ------------------------------------------------------------------------------ dQ gather
 // dQ[j][:] = sum of dpre rows listed in rev_rows[rev_ptr[j]..rev_ptr[j+1]) in ascending row id.
+// One wave per source node.  The in-edge list is filled with atomics (arbitrary order), so the wave first
+// sorts it (rank by counting, one ds_permute) and then streams the rows in ascending row id with eight
+// row loads in flight: fixed summation order -> bitwise reproducible, and enough bytes in flight for HBM.
+template <typename T>
+__device__ __forceinline__ void dq_row_load(const T* row, int col, bool ok, float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        u32x4 raw = {0u, 0u, 0u, 0u};
+        if (ok) raw = *reinterpret_cast<const u32x4*>(row + col);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned u = raw[w];
+            v[2 * w] = __builtin_bit_cast(float, u << 16);
+            v[2 * w + 1] = __builtin_bit_cast(float, u & 0xffff0000u);
+        }
+    } else {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (ok) {
+            a = *reinterpret_cast<const float4*>(row + col);
+            b = *reinterpret_cast<const float4*>(row + col + 4);
+        }
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void dq_gather_kernel(const T* __restrict__ dpre, int H1p,
                                                         const int* __restrict__ rev_ptr, const int* __restrict__ rev_rows,
@@ -452,35 +476,68 @@ __global__ __launch_bounds__(256) void dq_gather_kernel(const T* __restrict__ dp
     const int lane = threadIdx.x & 63;
     if (j >= N) return;
     const int lo = rev_ptr[j], hi = rev_ptr[j + 1];
-    constexpr int NC = 2;                                     // column passes: lane*4 + 256*c
-    float4 acc[NC];
+    const int deg = hi - lo;
+    // lane owns columns [8*lane, 8*lane+8) (pass 0) and [512 + 8*lane, ...) is never needed: H1p <= 512
+    const int col = lane * 8;
+    const bool ok = col < H1p;                                // H1p is a multiple of 8 on this path
+    float acc[8];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int last = -1;
-    for (int t = lo; t < hi; ++t) {
-        // next row id in ascending order: min over entries > last
-        int best = 0x7fffffff;
-        for (int e = lo + lane; e < hi; e += 64) {
-            const int r = rev_rows[e];
-            if (r > last && r < best) best = r;
-        }
+    for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+
+    if (deg <= 64) {
+        const int r = lane < deg ? rev_rows[lo + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int t = 0; t < deg; ++t) rank += (__shfl(r, t) < r) ? 1 : 0;      // row ids are distinct
+        // lanes >= deg hold INT_MAX: rank = deg (collide harmlessly on slot deg..; keep them out of the way)
+        const int slot = lane < deg ? rank : lane;
+        const int sorted = __builtin_amdgcn_ds_permute(slot << 2, r);
+        int t = 0;
+        for (; t + 8 <= deg; t += 8) {
+            float v[8][8];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
-        last = best;
-        const T* row = dpre + (long long)best * H1p;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int col = lane * 4 + 256 * c;
-            if (col < H1p) {
-                const float4 v = load4<T>(row + col);
-                acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w;
+            for (int u = 0; u < 8; ++u) {
+                const int row = __shfl(sorted, t + u);
+                dq_row_load<T>(dpre + (long long)row * H1p, col, ok, v[u]);
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] += v[u][c];
+        }
+        if (t < deg) {
+            float v[8][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = __shfl(sorted, min(t + u, deg - 1));
+                dq_row_load<T>(dpre + (long long)row * H1p, col, ok && (t + u < deg), v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] += v[u][c];       // + 0.0f for the masked rows: exact
+        }
+    } else {
+        int last = -1;
+        for (int t = lo; t < hi; ++t) {
+            // next row id in ascending order: min over entries > last
+            int best = 0x7fffffff;
+            for (int e = lo + lane; e < hi; e += 64) {
+                const int r = rev_rows[e];
+                if (r > last && r < best) best = r;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+            last = best;
+            float v[8];
+            dq_row_load<T>(dpre + (long long)best * H1p, col, ok, v);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] += v[c];
         }
     }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int col = lane * 4 + 256 * c;
-        if (col < H1p) *reinterpret_cast<float4*>(dQ + (long long)j * ldq + col) = acc[c];
+    if (ok) {
+        float* dst = dQ + (long long)j * ldq + col;
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
 }
 
@@ -649,7 +706,7 @@ hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p
 hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows, int N,
                             float* dQ, long long ldq, hipStream_t st) {
     if (N == 0) return hipSuccess;
-    if (H1p > 512 || (H1p & 3) || (ldq & 3)) return hipErrorInvalidValue;
+    if (H1p > 512 || (H1p & 7) || (ldq & 3)) return hipErrorInvalidValue;
     if (mode == 0)
         hipLaunchKernelGGL((dq_gather_kernel<float>), dim3(cdiv__(N, 4)), dim3(256), 0, st, (const float*)dpre, H1p,
                            rev_ptr, rev_rows, N, dQ, ldq);

@@ -178,6 +178,8 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
         f32x16 acc0, acc1;
 #pragma unroll
         for (int q = 0; q < 16; ++q) { acc0[q] = bias; acc1[q] = bias; }
+        float st_sum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        unsigned int st_msk = 0;
         if (wave_on) {
             const unsigned char* a0 = &As[buf][r * ROWB + h * 16];
             const unsigned char* a1 = a0 + 32 * ROWB;
@@ -198,7 +200,6 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
             const bool all_valid = (vbits == ~0ull);                              // wave-uniform
             const unsigned int vrow0 = (unsigned int)(vbits >> (4 * h));          // row block 0, this half
             const unsigned int vrow1 = (unsigned int)(vbits >> (32 + 4 * h));     // row block 1
-            const long long c0t = (long long)tile * (V2_ROWS / S);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const f32x16& acc = rb ? acc1 : acc0;
@@ -222,15 +223,15 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
                 }
                 const unsigned int other = __shfl_xor(pack, 32);
                 const unsigned int lo16 = h ? other : pack, hi16 = h ? pack : other;   // slots 0-3 / 4-7
+                // this lane stores centres c = 2h, 2h+1 of the row block; the stores themselves are issued
+                // at the end of the iteration (see below)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float sum = sums[c] + __shfl_xor(sums[c], 32);
-                    const long long centre = c0t + rb * 4 + c;
-                    if ((c >> 1) == h && centre < g.N) {
-                        out[centre * ldo + col] = sum;
-                        maskB[centre * H2 + col] =
-                            (unsigned char)(((lo16 >> (4 * c)) & 0xFu) | (((hi16 >> (4 * c)) & 0xFu) << 4));
-                    }
+                for (int cc = 0; cc < 2; ++cc) {
+                    const float mine = h ? sums[2 + cc] : sums[cc];
+                    const float theirs = h ? sums[cc] : sums[2 + cc];          // what the partner lane needs
+                    st_sum[rb][cc] = mine + __shfl_xor(theirs, 32);
+                    const int sh = 4 * (2 * h + cc);
+                    st_msk |= (((lo16 >> sh) & 0xFu) | (((hi16 >> sh) & 0xFu) << 4)) << (8 * (2 * rb + cc));
                 }
             }
         }
@@ -243,6 +244,21 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
         else { GN_V2_WRITE_H(buf ^ 1, 0, CH_A, NI_A); }
         if (gc0 == 0) s_jc[buf ^ 1][grow] = jc_n;
         ic_n = ic_nn; jc_n = ok_nn ? raw_nn : -1;
+        // Output stores LAST: vmcnt retires in order, so any gathered operand consumed after a store would
+        // also wait for that store's write acknowledgement.
+        if (wave_on) {
+            const long long c0t = (long long)tile * (V2_ROWS / S);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const long long centre = c0t + rb * 4 + 2 * h + cc;
+                    if (centre < g.N) {
+                        out[centre * ldo + col] = st_sum[rb][cc];
+                        maskB[centre * H2 + col] = (unsigned char)(st_msk >> (8 * (2 * rb + cc)));
+                    }
+                }
+        }
         __syncthreads();
     }
 #undef GN_V2_WRITE_H
@@ -293,16 +309,26 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
 
     const int grow = tid >> 3, gc0 = tid & 7;
     u32x4 preg[NI], qreg[NI];
+// All gathered chunks are consumed (-> LDS) before the first hbits store is issued: vmcnt retires in order,
+// so a store queued between two consumed loads would make the later wait include that store's write ack.
 #define GN_V2_WRITE_HT(buf_, tile_)                                                                   \
     {                                                                                                 \
         const long long rowg__ = (long long)(tile_) * V2_ROWS + grow;                                 \
         const bool rok__ = (tile_) < ntiles && rowg__ < main_rows;                                    \
+        unsigned int hb__[NI];                                                                        \
         _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
             const int c__ = cbeg + gc0 + 8 * i;                                                       \
             const int cc__ = c__ < cend ? c__ : cend - 1;                                             \
             const u32x4 hv__ = relu_sum_bf16x8(preg[i], qreg[i]);                                     \
             *reinterpret_cast<u32x4*>(&Hs[buf_][grow * HP + (cc__ - cbeg) * 16]) = hv__;              \
-            if (rok__) hbits[rowg__ * CHUNKS + cc__] = (unsigned char)nonzero_bits_bf16x8(hv__);      \
+            hb__[i] = nonzero_bits_bf16x8(hv__);                                                      \
+        }                                                                                             \
+        if (rok__) {                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                          \
+                const int c__ = cbeg + gc0 + 8 * i;                                                   \
+                const int cc__ = c__ < cend ? c__ : cend - 1;                                         \
+                hbits[rowg__ * CHUNKS + cc__] = (unsigned char)hb__[i];                               \
+            }                                                                                         \
         }                                                                                             \
     }
     // A-side operands of one tile: per k-step s the lane needs g_out and the slot byte of centre
@@ -424,8 +450,6 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
     constexpr int K2 = 256, KS2 = K2 / 16;         // contraction (H2)
     constexpr int DP = K2 * 2 + 16;                // dm tile pitch (b128 reads)
     constexpr int SP = K * 2 + 16;                 // dpre staging pitch
-    constexpr int CHUNKS = K / 8;
-    constexpr int CPT = (CHUNKS + 7) / 8;
     constexpr int HBW = (V2_ROWS * NB1 + NT - 1) / NT;   // hbits words per thread
     __shared__ __attribute__((aligned(16))) unsigned char Ds[2][V2_ROWS * DP];
     __shared__ __attribute__((aligned(16))) unsigned int Hb[2][V2_ROWS * NB1];
@@ -454,27 +478,29 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
     f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
     unsigned int mlo = 0, mhi = 0;
     unsigned int hbw[HBW];
+    bool dm_ok = false, hb_ok[HBW];
+// Loads only ISSUE here (addresses clamped in range); validity masks are applied in GN_V2_WRITE_DM, one
+// tile later, so that no s_waitcnt on these loads (and on the dpre stores queued before them) lands at the
+// top of the loop.
 #define GN_V2_LOAD_DM(tile_)                                                                          \
     {                                                                                                 \
         if (builder) {                                                                                \
             const long long c__ = (long long)(tile_) * 8 + bcl;                                       \
-            const bool ok__ = (tile_) < ntiles && c__ < g.N;                                          \
-            const long long cs__ = ok__ ? c__ : 0;                                                    \
+            dm_ok = (tile_) < ntiles && c__ < g.N;                                                    \
+            const long long cs__ = dm_ok ? c__ : 0;                                                   \
             const float* gp__ = gout + cs__ * ldg + bcc * 8;                                          \
             g0 = *reinterpret_cast<const f32x4*>(gp__);                                               \
             g1 = *reinterpret_cast<const f32x4*>(gp__ + 4);                                           \
             const unsigned int* mp__ = reinterpret_cast<const unsigned int*>(maskB + cs__ * K2 + bcc * 8); \
-            const unsigned int l__ = mp__[0], u__ = mp__[1];                                          \
-            mlo = ok__ ? l__ : 0u;                                                                    \
-            mhi = ok__ ? u__ : 0u;                                                                    \
+            mlo = mp__[0];                                                                            \
+            mhi = mp__[1];                                                                            \
         }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < HBW; ++i) {                                             \
             const int w__ = tid + NT * i;                        /* word index in [64][NB1] */        \
             const long long rowg__ = (long long)(tile_) * V2_ROWS + w__ / NB1;                        \
-            const bool okw__ = (tile_) < ntiles && w__ < V2_ROWS * NB1 && rowg__ < main_rows;         \
-            const long long idx__ = okw__ ? rowg__ * NB1 + (w__ % NB1) : 0;                           \
-            const unsigned int v__ = reinterpret_cast<const unsigned int*>(hbits)[idx__];             \
-            hbw[i] = okw__ ? v__ : 0u;                                                                \
+            hb_ok[i] = (tile_) < ntiles && w__ < V2_ROWS * NB1 && rowg__ < main_rows;                 \
+            const long long idx__ = hb_ok[i] ? rowg__ * NB1 + (w__ % NB1) : 0;                        \
+            hbw[i] = reinterpret_cast<const unsigned int*>(hbits)[idx__];                             \
         }                                                                                             \
     }
 #define GN_V2_WRITE_DM(buf_)                                                                          \
@@ -483,10 +509,11 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
             unsigned int gw__[4];                                                                     \
             gw__[0] = pack_bf16x2(g0[0], g0[1]); gw__[1] = pack_bf16x2(g0[2], g0[3]);                 \
             gw__[2] = pack_bf16x2(g1[0], g1[1]); gw__[3] = pack_bf16x2(g1[2], g1[3]);                 \
+            const unsigned int okm__ = dm_ok ? 0x01010101u : 0u;                                      \
             _Pragma("unroll") for (int si = 0; si < 4; ++si) {                                        \
                 const int slot__ = 4 * bsh + si;                                                      \
-                const unsigned int flo__ = (mlo >> slot__) & 0x01010101u;                             \
-                const unsigned int fhi__ = (mhi >> slot__) & 0x01010101u;                             \
+                const unsigned int flo__ = (mlo >> slot__) & okm__;                                   \
+                const unsigned int fhi__ = (mhi >> slot__) & okm__;                                   \
                 u32x4 dw__;                                                                           \
                 _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                    \
                     const unsigned int f__ = jj < 2 ? flo__ : fhi__;                                  \
@@ -500,7 +527,7 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
         }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < HBW; ++i) {                                             \
             const int w__ = tid + NT * i;                                                             \
-            if (w__ < V2_ROWS * NB1) Hb[buf_][w__] = hbw[i];                                          \
+            if (w__ < V2_ROWS * NB1) Hb[buf_][w__] = hb_ok[i] ? hbw[i] : 0u;                          \
         }                                                                                             \
     }
 
@@ -511,7 +538,7 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
     GN_V2_WRITE_DM(0);
     __syncthreads();
 
-    const int grow = tid >> 3, gc0 = tid & 7;
+    const int srow = tid / NB1, sc0 = tid % NB1;
     int buf = 0;
     for (; tile < tile_end; ++tile, buf ^= 1) {
         GN_V2_LOAD_DM(tile + 1);
@@ -523,18 +550,16 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
             const unsigned char* p1 = p0 + 32 * DP;
             bf16x8 f0 = *reinterpret_cast<const bf16x8*>(p0);
             bf16x8 f1 = *reinterpret_cast<const bf16x8*>(p1);
-            bf16x8 n0 = *reinterpret_cast<const bf16x8*>(p0 + 32);
-            bf16x8 n1 = *reinterpret_cast<const bf16x8*>(p1 + 32);
 #pragma unroll
             for (int s = 0; s < KS2; ++s) {
-                bf16x8 m0 = n0, m1 = n1;
-                if (s + 2 < KS2) {
-                    m0 = *reinterpret_cast<const bf16x8*>(p0 + (s + 2) * 32);
-                    m1 = *reinterpret_cast<const bf16x8*>(p1 + (s + 2) * 32);
+                bf16x8 n0 = f0, n1 = f1;
+                if (s + 1 < KS2) {
+                    n0 = *reinterpret_cast<const bf16x8*>(p0 + (s + 1) * 32);
+                    n1 = *reinterpret_cast<const bf16x8*>(p1 + (s + 1) * 32);
                 }
                 a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, wa[s], a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, wa[s], a1, 0, 0, 0);
-                f0 = n0; f1 = n1; n0 = m0; n1 = m1;
+                f0 = n0; f1 = n1;
             }
 
             // ---- epilogue: (.) [h > 0], slot sums -> dP, dpre tile -> LDS staging
@@ -564,23 +589,24 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
                 }
             }
         }
-        __syncthreads();                                  // staging tile complete
+        // The next tile's operands go to LDS BEFORE this tile's dpre stores are issued: vmcnt retires in
+        // order, so consuming those loads after the stores would wait for the stores' write acks every tile.
+        GN_V2_WRITE_DM(buf ^ 1);
+        __syncthreads();                                  // staging tile + next dm tile complete
 
-        // cooperative, coalesced store of the dpre tile (full 16-byte chunks of each row)
-        if (tid < V2_ROWS * 8) {
-            const long long rowg = (long long)tile * V2_ROWS + grow;
+        // cooperative store of the dpre tile: NB1 threads per row, 4 chunks of 16 bytes each at a fixed
+        // stride (immediate offsets: one LDS and one global base address per thread, nothing to spill)
+        if (tid < V2_ROWS * NB1) {
+            const long long rowg = (long long)tile * V2_ROWS + srow;
             if (rowg < main_rows) {
+                const unsigned char* sp = &Stage[srow * SP + sc0 * 16];
+                unsigned char* gp = reinterpret_cast<unsigned char*>(dpre + rowg * K) + sc0 * 16;
 #pragma unroll
-                for (int i = 0; i < CPT; ++i) {
-                    const int c = gc0 + 8 * i;
-                    const int cc = c < CHUNKS ? c : CHUNKS - 1;
-                    *reinterpret_cast<u32x4*>(dpre + rowg * K + cc * 8) =
-                        *reinterpret_cast<const u32x4*>(&Stage[grow * SP + cc * 16]);
-                }
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<u32x4*>(gp + i * NB1 * 16) = *reinterpret_cast<const u32x4*>(sp + i * NB1 * 16);
             }
         }
-        GN_V2_WRITE_DM(buf ^ 1);
-        __syncthreads();
+        __syncthreads();                                  // Stage may be overwritten by the next tile
     }
 #undef GN_V2_LOAD_DM
 #undef GN_V2_WRITE_DM
