@@ -34,21 +34,21 @@ SIGNATURES = {
     "gn_edge_index_to_table": (I32, [P, I64, I32, I32, P, P, P, P, P]),
     "gn_ptr_to_batch": (I32, [P, I32, P, P]),
     "gn_graph_globals": (I32, [P, I64, I32, P, I32, P, P, I32, P, P, P]),
-    "gn_concat_globals": (I32, [P, I64, I32, P, I32, P, I32, P, I32, P]),
-    "gn_linear_fwd": (I32, [I32, I32, P, P, P, P, I32, P, I32, I32, I32, P, P, I64, I32, I32, P, I64, I32, P]),
+    "gn_concat_globals": (I32, [P, I64, I32, P, I32, P, I32, P, I32, I32, P]),
+    "gn_linear_fwd": (I32, [I32, I32, P, I32, P, P, P, I32, P, I32, I32, I32, P, P, I32, I64, I32, I32, P, I64, I32, P]),
     "gn_linear_wgrad_parts": (I32, [I32, I32, I32, I32, P]),
-    "gn_linear_wgrad": (I32, [I32, P, I64, I32, I32, P, P, P, I32, P, P, P, P, I32, P]),
+    "gn_linear_wgrad": (I32, [I32, P, I32, I64, I32, I32, P, I32, P, P, I32, P, P, P, P, I32, P]),
     "gn_colsum_blocks": (I32, [I32]),
     "gn_colsum": (I32, [P, I64, I32, I32, P, P, I32, P]),
     "gn_reduce_slabs": (I32, [P, I32, I64, P, I32, P]),
     "gn_edgeconv_saved_bytes": (I64, [I32, I32, I32, I32]),
-    "gn_edgeconv_fwd": (I32, [I32, P, P, P, P, I32, I32, P, I32, P, P, I32, P, I64, P, P]),
+    "gn_edgeconv_fwd": (I32, [I32, P, P, P, P, I32, I32, P, I32, P, P, I32, P, I64, P, P, I32, P, P]),
     "gn_edgeconv_bwd": (I32, [I32, P, P, P, P, I32, I32, P, I32, I32, P, I64, P, P, I32, P, P, I64, P]),
     "gn_edgeconv_dw2_slabs": (I32, [I32, I32, I32, I32, I32]),
     "gn_edgeconv_dw2": (I32, [I32, P, P, P, P, I32, I32, P, I32, I32, I32, P, I64, P, P, P, P]),
     "gn_edgeconv_dq_gather": (I32, [I32, P, I32, P, P, I32, P, I64, P]),
     "gn_segment_pool_fwd": (I32, [P, I64, I32, P, I32, P, I32, P, P, P, P]),
-    "gn_segment_pool_bwd": (I32, [P, I32, P, P, I32, P, I32, P, P, P, I64, P, I64, P]),
+    "gn_segment_pool_bwd": (I32, [P, I32, P, P, I32, P, I32, P, P, P, I64, P, I64, I32, P]),
 }
 
 

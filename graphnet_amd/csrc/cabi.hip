@@ -19,7 +19,7 @@ int bad(const char* where, const char* what) {
 }
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-bool make_segs(gn::Segs& s, int nseg, const float* const* p, const int64_t* ld, const int32_t* width,
+bool make_segs(gn::Segs& s, int nseg, const void* const* p, const int64_t* ld, const int32_t* width,
                const int32_t* kpad) {
     if (nseg < 1 || nseg > gn::MAXSEG) return false;
     std::memset(&s, 0, sizeof(s));
@@ -95,39 +95,39 @@ int gn_graph_globals(const float* x, int64_t ldx, int32_t F, const int32_t* ptr,
     return fail(gn::launch_globals(x, ldx, F, ptr, B, nbr, ovf, K, n_pulses, out, S(stream)), "gn_graph_globals");
 }
 int gn_concat_globals(const float* x, int64_t ldx, int32_t F, const float* gv, int32_t G, const int32_t* batch,
-                      int32_t N, float* x0, int32_t ld0, void* stream) {
+                      int32_t N, void* x0, int32_t ld0, int32_t out_lowp, void* stream) {
     if (ld0 < F + G) return bad("gn_concat_globals", "ld0 < F+G");
-    return fail(gn::launch_concat_globals(x, ldx, F, gv, G, batch, N, x0, ld0, S(stream)), "gn_concat_globals");
+    return fail(gn::launch_concat_globals(x, ldx, F, gv, G, batch, N, x0, ld0, out_lowp, S(stream)), "gn_concat_globals");
 }
 
-int gn_linear_fwd(int32_t mode, int32_t nseg, const float* const* a_ptr, const int64_t* a_ld, const int32_t* a_width,
-                  const int32_t* a_kpad, int32_t M, const void* Wp, int32_t Kp, int32_t Npad, int32_t Nreal,
-                  const float* bias, const float* gate, int64_t ldgate, int32_t relu, int32_t accum, void* C,
-                  int64_t ldc, int32_t out_lowp, void* stream) {
+int gn_linear_fwd(int32_t mode, int32_t nseg, const void* const* a_ptr, int32_t a_lowp, const int64_t* a_ld,
+                  const int32_t* a_width, const int32_t* a_kpad, int32_t M, const void* Wp, int32_t Kp, int32_t Npad,
+                  int32_t Nreal, const float* bias, const void* gate, int32_t gate_lowp, int64_t ldgate, int32_t relu,
+                  int32_t accum, void* C, int64_t ldc, int32_t out_lowp, void* stream) {
     gn::Segs a;
     if (!make_segs(a, nseg, a_ptr, a_ld, a_width, a_kpad)) return bad("gn_linear_fwd", "bad A segments (1..6, 16-byte aligned)");
     if (mode != 0 && mode != 1) return bad("gn_linear_fwd", "mode");
-    if (out_lowp && (mode == 0 || accum)) return bad("gn_linear_fwd", "low-precision output needs bf16 mode, no accumulate");
+    if ((out_lowp || a_lowp || gate_lowp) && mode == 0) return bad("gn_linear_fwd", "bf16 tensors need bf16 mode");
     if (Npad % 128 || Nreal > Npad || (reinterpret_cast<uintptr_t>(Wp) & 15)) return bad("gn_linear_fwd", "Wp must be [Npad%128==0][Kp], 16-byte aligned");
     gn::Epi e;
-    e.bias = bias; e.gate = gate; e.ldgate = ldgate; e.relu = relu; e.accum = accum;
-    hipError_t r = gn::launch_gemm_nt(mode, a, M, Wp, Kp, Npad, Nreal, e, C, ldc, out_lowp, S(stream));
-    if (r == hipErrorInvalidValue) return bad("gn_linear_fwd", "segment widths/pitches must be multiples of 4, kpad multiples of 32 summing to Kp");
+    e.bias = bias; e.gate = gate; e.ldgate = ldgate; e.relu = relu; e.accum = accum; e.gate_lowp = gate_lowp;
+    hipError_t r = gn::launch_gemm_nt(mode, a, a_lowp, M, Wp, Kp, Npad, Nreal, e, C, ldc, out_lowp, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_linear_fwd", "segment widths/pitches must be multiples of 4 (8 for bf16 rows), kpad multiples of 32 summing to Kp");
     return fail(r, "gn_linear_fwd");
 }
 int32_t gn_linear_wgrad_parts(int32_t mode, int32_t M, int32_t N1, int32_t nseg, const int32_t* x_width) {
     if (nseg < 1 || nseg > gn::MAXSEG || !x_width) return -1;
     return gn::gemm_tn_parts(mode, M, N1, x_width, nseg);
 }
-int gn_linear_wgrad(int32_t mode, const float* dY, int64_t lddy, int32_t N1, int32_t nseg, const float* const* x_ptr,
-                    const int64_t* x_ld, const int32_t* x_width, int32_t M, float* slab, float* db_part, float* dW,
-                    float* db, int32_t accum, void* stream) {
+int gn_linear_wgrad(int32_t mode, const void* dY, int32_t dy_lowp, int64_t lddy, int32_t N1, int32_t nseg,
+                    const void* const* x_ptr, int32_t x_lowp, const int64_t* x_ld, const int32_t* x_width, int32_t M,
+                    float* slab, float* db_part, float* dW, float* db, int32_t accum, void* stream) {
     gn::Segs x;
     if (!make_segs(x, nseg, x_ptr, x_ld, x_width, nullptr)) return bad("gn_linear_wgrad", "bad X segments");
     if (reinterpret_cast<uintptr_t>(dY) & 15) return bad("gn_linear_wgrad", "dY must be 16-byte aligned");
     if (db && !db_part) return bad("gn_linear_wgrad", "db needs db_part scratch");
-    hipError_t r = gn::launch_gemm_tn(mode, dY, lddy, N1, x, M, slab, db_part, dW, db, accum, S(stream));
-    if (r == hipErrorInvalidValue) return bad("gn_linear_wgrad", "widths/pitches/N1 must be multiples of 4");
+    hipError_t r = gn::launch_gemm_tn(mode, dY, dy_lowp, lddy, N1, x, x_lowp, M, slab, db_part, dW, db, accum, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_linear_wgrad", "widths/pitches/N1 must be multiples of 4 (8 for bf16 rows); bf16 rows need bf16 mode");
     return fail(r, "gn_linear_wgrad");
 }
 int32_t gn_colsum_blocks(int32_t M) { return gn::colsum_blocks(M); }
@@ -143,20 +143,22 @@ int64_t gn_edgeconv_saved_bytes(int32_t N, int32_t K, int32_t H1p, int32_t H2) {
 }
 int gn_edgeconv_fwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
                     const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, const void* W2p,
-                    const float* b2, int32_t H2, float* out, int64_t ldo, void* saved, void* stream) {
+                    const float* b2, int32_t H2, void* out, int64_t ldo, float* coords, const int32_t* coord_cols_host,
+                    int32_t ncoord, void* saved, void* stream) {
     if (K < 1 || K > 32 || H1p % 32 || H2 < 1) return bad("gn_edgeconv_fwd", "need 1<=K<=32, H1p%32==0");
     if ((reinterpret_cast<uintptr_t>(PQ) & 15) || (reinterpret_cast<uintptr_t>(W2p) & 15) ||
         (reinterpret_cast<uintptr_t>(saved) & 15)) return bad("gn_edgeconv_fwd", "alignment");
+    if (ncoord < 0 || ncoord > 8 || (ncoord > 0 && coords && !coord_cols_host)) return bad("gn_edgeconv_fwd", "0..8 coordinate columns");
     return fail(gn::launch_edge_fwd(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, W2p, b2, H2, out,
-                                    ldo, saved, S(stream)), "gn_edgeconv_fwd");
+                                    ldo, coords, coord_cols_host, ncoord, saved, S(stream)), "gn_edgeconv_fwd");
 }
 int32_t gn_edgeconv_dw2_slabs(int32_t mode, int32_t N, int32_t K, int32_t H1p, int32_t H2) {
     return gn::edge_dw2_slabs(mode, N, K, H1p, H2);
 }
 int gn_edgeconv_dw2(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
                     const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H1, int32_t H2,
-                    const float* gout, int64_t ldg, void* saved, float* slab, float* db2_part, void* stream) {
-    if (K < 1 || K > 32 || H1p % 32 || H1 > H1p || (ldg & 3) || (H2 & 3) || N < 1 ||
+                    const void* gout, int64_t ldg, void* saved, float* slab, float* db2_part, void* stream) {
+    if (K < 1 || K > 32 || H1p % 32 || H1 > H1p || (ldg & (mode ? 7 : 3)) || (H2 & 3) || N < 1 ||
         (reinterpret_cast<uintptr_t>(gout) & 15))
         return bad("gn_edgeconv_dw2", "bad shapes");
     return fail(gn::launch_edge_dw2(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, H1, H2, gout, ldg,
@@ -164,17 +166,18 @@ int gn_edgeconv_dw2(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre,
 }
 int gn_edgeconv_bwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
                     const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H2,
-                    const float* gout, int64_t ldg, const void* saved, const void* W2Tp, int32_t H2p, void* dpre,
-                    float* dP, int64_t ldp, void* stream) {
-    if (K < 1 || K > 32 || H1p % 32 || H2p % 32 || H2p < H2 || (ldg & 3) || (reinterpret_cast<uintptr_t>(gout) & 15))
-        return bad("gn_edgeconv_bwd", "need 1<=K<=32, H1p%32==0, H2p%32==0, gout 16-byte aligned with pitch%4==0");
+                    const void* gout, int64_t ldg, const void* saved, const void* W2Tp, int32_t H2p, void* dpre,
+                    void* dP, int64_t ldp, void* stream) {
+    if (K < 1 || K > 32 || H1p % 32 || H2p % 32 || H2p < H2 || (ldg & (mode ? 7 : 3)) || (ldp & (mode ? 7 : 3)) ||
+        (reinterpret_cast<uintptr_t>(gout) & 15) || (reinterpret_cast<uintptr_t>(dP) & 15))
+        return bad("gn_edgeconv_bwd", "need 1<=K<=32, H1p%32==0, H2p%32==0, gout/dP 16-byte aligned with 16-byte row pitches");
     return fail(gn::launch_edge_bwd(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, H2, gout, ldg,
                                     saved, W2Tp, H2p, dpre, dP, ldp, S(stream)), "gn_edgeconv_bwd");
 }
 int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int32_t* rev_ptr, const int32_t* rev_rows,
-                          int32_t N, float* dQ, int64_t ldq, void* stream) {
+                          int32_t N, void* dQ, int64_t ldq, void* stream) {
     hipError_t r = gn::launch_dq_gather(mode, dpre, H1p, rev_ptr, rev_rows, N, dQ, ldq, S(stream));
-    if (r == hipErrorInvalidValue) return bad("gn_edgeconv_dq_gather", "need H1p <= 512, H1p%8==0, ldq%4==0");
+    if (r == hipErrorInvalidValue) return bad("gn_edgeconv_dq_gather", "need H1p <= 512, H1p%8==0, 16-byte dQ row pitch");
     return fail(r, "gn_edgeconv_dq_gather");
 }
 
@@ -186,9 +189,9 @@ int gn_segment_pool_fwd(const float* x, int64_t ldx, int32_t C, const int32_t* p
 }
 int gn_segment_pool_bwd(const float* gout, int32_t C, const int32_t* ptr, const int32_t* batch, int32_t N,
                         const int32_t* codes_host, int32_t ns, const int32_t* argmin, const int32_t* argmax,
-                        const float* gate, int64_t ldgate, float* dx, int64_t lddx, void* stream) {
+                        const float* gate, int64_t ldgate, void* dx, int64_t lddx, int32_t dx_lowp, void* stream) {
     hipError_t r = gn::launch_pool_bwd(gout, C, ptr, batch, N, codes_host, ns, argmin, argmax, gate, ldgate, dx, lddx,
-                                       S(stream));
+                                       dx_lowp, S(stream));
     if (r == hipErrorInvalidValue) return bad("gn_segment_pool_bwd", "1..4 pooling schemes");
     return fail(r, "gn_segment_pool_bwd");
 }

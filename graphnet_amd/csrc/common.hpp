@@ -141,7 +141,7 @@ template <typename T> __device__ __forceinline__ void zero_acc(T& a) {
 // segment s contributes `width` real columns, padded to `kpad` (multiple of BK) in K space.
 constexpr int MAXSEG = 6;
 struct Segs {
-    const float* p[MAXSEG];
+    const void* p[MAXSEG];   // float or bf16 rows (the launcher's a_lowp / x_lowp flag says which)
     long long ld[MAXSEG];
     int width[MAXSEG];
     int kpad[MAXSEG];
@@ -151,11 +151,22 @@ struct Segs {
 // epilogue of the NT GEMM
 struct Epi {
     const float* bias;      // [N] or null
-    const float* gate;      // [M, ldgate] or null: output *= (gate > 0)
+    const void* gate;       // [M, ldgate] or null: output *= (gate > 0); fp32, or bf16 when gate_lowp
     long long ldgate;
     int relu;               // max(v, 0)
-    int accum;              // C += v (fp32 outputs only)
+    int accum;              // C += v (read-modify-write in C's own type)
+    int gate_lowp;
 };
+
+// fp32 copy of a few output columns (the coordinates the next layer's k-NN runs on) kept beside a
+// bf16 activation tensor: coords[i][d] = out_f32[i][c[d]], pitch 8
+struct CoordCols { int n; int c[8]; };
+__device__ __forceinline__ void coord_store(float* coords, const CoordCols& cc, long long i, int col, float v, bool add) {
+    if (!coords) return;
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+        if (d < cc.n && cc.c[d] == col) { float* p = coords + i * 8 + d; *p = add ? *p + v : v; }
+}
 
 // neighbour table + overflow list of one layer's graph
 struct EdgeGraph {

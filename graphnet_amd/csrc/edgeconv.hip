@@ -51,7 +51,8 @@ template <typename T, int S, bool OVF>
 __global__ __launch_bounds__(256) void edge_fwd_kernel(
     EdgeGraph g, const T* __restrict__ PQ, int H1p,            // PQ: [N, 2*H1p], P then Q
     const T* __restrict__ W2p, const float* __restrict__ b2, int H2,   // W2p: [H2pad128][H1p]
-    float* __restrict__ out, long long ldo,                    // [N, H2] (+= for OVF)
+    T* __restrict__ out, long long ldo,                        // [N, H2] in the compute type (+= for OVF)
+    float* __restrict__ coords, CoordCols cc,                  // optional fp32 copy of a few columns
     unsigned int* __restrict__ maskbits)                       // [rows][H2w], H2w = ceil(H2/32)
 {
     constexpr int ROWB = TileCfg<T>::ROWB;
@@ -159,7 +160,11 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rl = rbase + acc_row(r, h);
-                    if (colok && s_jc[rl] >= 0) out[(long long)s_ic[rl] * ldo + col] += v[r];
+                    if (colok && s_jc[rl] >= 0) {
+                        T* o = out + (long long)s_ic[rl] * ldo + col;
+                        *o = from_f32<T>(to_f32(*o) + v[r]);
+                        coord_store(coords, cc, s_ic[rl], col, v[r], true);
+                    }
                 }
             } else {
                 constexpr int CPT = 32 / S;          // centres per 32-row tile
@@ -172,7 +177,10 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(
                     for (int q = 0; q < RPC; ++q) s += v[c * RPC + q];
                     s += __shfl_xor(s, 32);
                     const bool mine = (CPT == 1) ? (h == 0) : ((c * 2 / CPT) == h);
-                    if (mine && colok && c0 + c < g.N) out[(c0 + c) * ldo + col] = s;
+                    if (mine && colok && c0 + c < g.N) {
+                        out[(c0 + c) * ldo + col] = from_f32<T>(s);
+                        coord_store(coords, cc, c0 + c, col, s, false);
+                    }
                 }
             }
         }
@@ -183,12 +191,12 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(
 template <typename T, int S, bool OVF>
 __global__ __launch_bounds__(256) void edge_bwd_kernel(
     EdgeGraph g, const T* __restrict__ PQ, int H1p, int H2,
-    const float* __restrict__ gout, long long ldg,             // [N, >=H2] gradient of conv output
+    const T* __restrict__ gout, long long ldg,                 // [N, >=H2] gradient of conv output (compute type)
     const unsigned int* __restrict__ maskbits,
     const T* __restrict__ W2Tp,                                // [H1pad128][H2p] (W2 transposed, packed)
     int H2p,                                                   // H2 padded to 32
     T* __restrict__ dpre,                                      // [rows][H1p]
-    float* __restrict__ dP, long long ldp)                     // [N, H1p] (= / += for OVF)
+    T* __restrict__ dP, long long ldp)                         // [N, H1p] in the compute type (= / += for OVF)
 {
     constexpr int ROWB = TileCfg<T>::ROWB;
     constexpr int BCHROW = BK * (int)sizeof(T) / 16;
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(
             f32x4 a = {0.f, 0.f, 0.f, 0.f};                                                               \
             if (ok[i] && kc < H2) {                                                                       \
                 const unsigned int w = maskbits[(rowbase + r0 + 32 * i) * H2w + (kb)] >> c4;              \
-                const float4 gv = *reinterpret_cast<const float4*>(gout + (long long)ic[i] * ldg + kc);   \
+                const float4 gv = load4<T>(gout + (long long)ic[i] * ldg + kc);                           \
                 a[0] = (w & 1u) ? gv.x : 0.f; a[1] = (w & 2u) ? gv.y : 0.f;                               \
                 a[2] = (w & 4u) ? gv.z : 0.f; a[3] = (w & 8u) ? gv.w : 0.f;                               \
             }                                                                                             \
@@ -294,7 +302,10 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rl = rbase + acc_row(r, h);
-                    if (colok && s_jc[rl] >= 0) dP[(long long)s_ic[rl] * ldp + col] += v[r];
+                    if (colok && s_jc[rl] >= 0) {
+                        T* o = dP + (long long)s_ic[rl] * ldp + col;
+                        *o = from_f32<T>(to_f32(*o) + v[r]);
+                    }
                 }
             } else {
                 constexpr int CPT = 32 / S, RPC = 16 / CPT;
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(
                     for (int q = 0; q < RPC; ++q) s += v[c * RPC + q];
                     s += __shfl_xor(s, 32);
                     const bool mine = (CPT == 1) ? (h == 0) : ((c * 2 / CPT) == h);
-                    if (mine && colok && c0 + c < g.N) dP[(c0 + c) * ldp + col] = s;
+                    if (mine && colok && c0 + c < g.N) dP[(c0 + c) * ldp + col] = from_f32<T>(s);
                 }
             }
         }
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(
 template <typename T, int S>
 __global__ __launch_bounds__(256) void edge_dw2_kernel(
     EdgeGraph g, const T* __restrict__ PQ, int H1p, int H1, int H2,
-    const float* __restrict__ gout, long long ldg, const unsigned int* __restrict__ maskbits,
+    const T* __restrict__ gout, long long ldg, const unsigned int* __restrict__ maskbits,
     long long row_begin, long long rows_per_split, float* __restrict__ slab, float* __restrict__ db2_part, int n2_tiles)
 {
     constexpr int ROWB = TileCfg<T>::ROWB;
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(256) void edge_dw2_kernel(
             const int ck = k1_0 + cb + 32 * i;                                                            \
             if (jc >= 0 && ca < H2) {                                                                     \
                 const unsigned int w = maskbits[row * H2w + (ca >> 5)] >> (ca & 31);                      \
-                const float4 gv = *reinterpret_cast<const float4*>(gout + (long long)ic * ldg + ca);      \
+                const float4 gv = load4<T>(gout + (long long)ic * ldg + ca);                              \
                 a[0] = (w & 1u) ? gv.x : 0.f; a[1] = (w & 2u) ? gv.y : 0.f;                               \
                 a[2] = (w & 4u) ? gv.z : 0.f; a[3] = (w & 8u) ? gv.w : 0.f;                               \
             }                                                                                             \
@@ -471,7 +482,7 @@ __device__ __forceinline__ void dq_row_load(const T* row, int col, bool ok, floa
 template <typename T>
 __global__ __launch_bounds__(256) void dq_gather_kernel(const T* __restrict__ dpre, int H1p,
                                                         const int* __restrict__ rev_ptr, const int* __restrict__ rev_rows,
-                                                        int N, float* __restrict__ dQ, long long ldq) {
+                                                        int N, T* __restrict__ dQ, long long ldq) {
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (j >= N) return;
@@ -535,9 +546,9 @@ __global__ __launch_bounds__(256) void dq_gather_kernel(const T* __restrict__ dp
         }
     }
     if (ok) {
-        float* dst = dQ + (long long)j * ldq + col;
-        *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        T* dst = dQ + (long long)j * ldq + col;
+        store4<T>(dst, acc[0], acc[1], acc[2], acc[3]);
+        store4<T>(dst + 4, acc[4], acc[5], acc[6], acc[7]);
     }
 }
 
@@ -563,13 +574,14 @@ long long edge_dw2_splits(long long rows) {
     }
 
 hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
-                              float* out, long long ldo, unsigned char* maskB, int num_cus, hipStream_t st);
-hipError_t launch_edge_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
+                              void* out, long long ldo, float* coords, const CoordCols& cc, unsigned char* maskB,
+                              int num_cus, hipStream_t st);
+hipError_t launch_edge_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout,
                               long long ldg, const unsigned char* maskB, unsigned char* hbits, float* slab,
                               float* db2_part, int num_cus, hipStream_t st);
-hipError_t launch_edge_bwd_v2(const EdgeGraph& g, int H1p, int H2, const float* gout, long long ldg,
+hipError_t launch_edge_bwd_v2(const EdgeGraph& g, int H1p, int H2, const void* gout, long long ldg,
                               const unsigned char* maskB, const unsigned char* hbits, const void* W2Tp, int H2p,
-                              void* dpre, float* dP, long long ldp, int num_cus, hipStream_t st);
+                              void* dpre, void* dP, long long ldp, int num_cus, hipStream_t st);
 bool edge_v2_shape_ok(int K, int H1p, int H2);
 int edge_dw2_v2_parts(int N, int H1p, int num_cus);
 constexpr int DW2_OVF_SPLITS = 8;
@@ -586,17 +598,18 @@ int device_cus() {
 
 template <typename T>
 static hipError_t edge_fwd_t(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
-                             float* out, long long ldo, unsigned int* maskbits, bool main_rows, hipStream_t st) {
+                             void* out, long long ldo, float* coords, const CoordCols& cc, unsigned int* maskbits,
+                             bool main_rows, hipStream_t st) {
     if (g.N == 0) return hipSuccess;
     const int S_ = edge_slots(g.K);
     const int ny = cdiv__(H2, EBN);
     GN_DISPATCH_S(S_, {
         if (main_rows)
             hipLaunchKernelGGL((edge_fwd_kernel<T, S, false>), dim3(cdiv__((long long)g.N * S, EBM), ny), dim3(256), 0, st,
-                               g, (const T*)PQ, H1p, (const T*)W2p, b2, H2, out, ldo, maskbits);
+                               g, (const T*)PQ, H1p, (const T*)W2p, b2, H2, (T*)out, ldo, coords, cc, maskbits);
         if (g.ovf_cnt)
             hipLaunchKernelGGL((edge_fwd_kernel<T, S, true>), dim3(cdiv__(g.N, EBM), ny), dim3(256), 0, st,
-                               g, (const T*)PQ, H1p, (const T*)W2p, b2, H2, out, ldo, maskbits);
+                               g, (const T*)PQ, H1p, (const T*)W2p, b2, H2, (T*)out, ldo, coords, cc, maskbits);
     });
     return hipGetLastError();
 }
@@ -608,25 +621,32 @@ static bool use_v2(int mode, const EdgeGraph& g, int H1p, int H2) {
     return mode == 1 && v2_enabled() && edge_v2_shape_ok(g.K, H1p, H2);
 }
 
+// out is float in mode 0 and bf16 in mode 1; coords (optional, [N][8] fp32) receives the columns
+// coord_cols[0..ncoord) of the fp32 result (the next layer's k-NN coordinates).
 hipError_t launch_edge_fwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2,
-                           int H2, float* out, long long ldo, void* saved, hipStream_t st) {
-    if (H1p % BK || g.K > 32) return hipErrorInvalidValue;
+                           int H2, void* out, long long ldo, float* coords, const int* coord_cols, int ncoord,
+                           void* saved, hipStream_t st) {
+    if (H1p % BK || g.K > 32 || ncoord < 0 || ncoord > 8) return hipErrorInvalidValue;
+    CoordCols cc;
+    cc.n = coords ? ncoord : 0;
+    for (int d = 0; d < 8; ++d) cc.c[d] = (d < cc.n) ? coord_cols[d] : -1;
+    if (cc.n == 0) coords = nullptr;
     const SavedLayout L = saved_layout(g.N, edge_slots(g.K), H1p, H2);
     unsigned char* sb = reinterpret_cast<unsigned char*>(saved);
     unsigned int* words = reinterpret_cast<unsigned int*>(sb + L.off_words);
-    if (mode == 0) return edge_fwd_t<float>(g, PQ, H1p, W2p, b2, H2, out, ldo, words, true, st);
+    if (mode == 0) return edge_fwd_t<float>(g, PQ, H1p, W2p, b2, H2, out, ldo, coords, cc, words, true, st);
     // bf16: persistent weights-stationary kernel for the table rows when the shape allows it
     const bool v2 = use_v2(mode, g, H1p, H2);
     if (v2) {
-        hipError_t e = launch_edge_fwd_v2(g, PQ, H1p, W2p, b2, H2, out, ldo, sb + L.off_maskB, device_cus(), st);
+        hipError_t e = launch_edge_fwd_v2(g, PQ, H1p, W2p, b2, H2, out, ldo, coords, cc, sb + L.off_maskB, device_cus(), st);
         if (e != hipSuccess) return e;
     }
-    return edge_fwd_t<__bf16>(g, PQ, H1p, W2p, b2, H2, out, ldo, words, !v2, st);
+    return edge_fwd_t<__bf16>(g, PQ, H1p, W2p, b2, H2, out, ldo, coords, cc, words, !v2, st);
 }
 
 template <typename T>
-static hipError_t edge_bwd_t(const EdgeGraph& g, const void* PQ, int H1p, int H2, const float* gout, long long ldg,
-                             const unsigned int* maskbits, const void* W2Tp, int H2p, void* dpre, float* dP,
+static hipError_t edge_bwd_t(const EdgeGraph& g, const void* PQ, int H1p, int H2, const void* gout, long long ldg,
+                             const unsigned int* maskbits, const void* W2Tp, int H2p, void* dpre, void* dP,
                              long long ldp, bool main_rows, hipStream_t st) {
     if (g.N == 0) return hipSuccess;
     const int S_ = edge_slots(g.K);
@@ -634,17 +654,20 @@ static hipError_t edge_bwd_t(const EdgeGraph& g, const void* PQ, int H1p, int H2
     GN_DISPATCH_S(S_, {
         if (main_rows)
             hipLaunchKernelGGL((edge_bwd_kernel<T, S, false>), dim3(cdiv__((long long)g.N * S, EBM), ny), dim3(256), 0, st,
-                               g, (const T*)PQ, H1p, H2, gout, ldg, maskbits, (const T*)W2Tp, H2p, (T*)dpre, dP, ldp);
+                               g, (const T*)PQ, H1p, H2, (const T*)gout, ldg, maskbits, (const T*)W2Tp, H2p, (T*)dpre,
+                               (T*)dP, ldp);
         if (g.ovf_cnt)
             hipLaunchKernelGGL((edge_bwd_kernel<T, S, true>), dim3(cdiv__(g.N, EBM), ny), dim3(256), 0, st,
-                               g, (const T*)PQ, H1p, H2, gout, ldg, maskbits, (const T*)W2Tp, H2p, (T*)dpre, dP, ldp);
+                               g, (const T*)PQ, H1p, H2, (const T*)gout, ldg, maskbits, (const T*)W2Tp, H2p, (T*)dpre,
+                               (T*)dP, ldp);
     });
     return hipGetLastError();
 }
-hipError_t launch_edge_bwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H2, const float* gout,
+// gout and dP are float in mode 0 and bf16 in mode 1
+hipError_t launch_edge_bwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H2, const void* gout,
                            long long ldg, const void* saved, const void* W2Tp, int H2p, void* dpre,
-                           float* dP, long long ldp, hipStream_t st) {
-    if (H1p % BK || H2p % BK || g.K > 32 || (ldg & 3)) return hipErrorInvalidValue;
+                           void* dP, long long ldp, hipStream_t st) {
+    if (H1p % BK || H2p % BK || g.K > 32 || (ldg & (mode ? 7 : 3)) || (ldp & (mode ? 7 : 3))) return hipErrorInvalidValue;
     const SavedLayout L = saved_layout(g.N, edge_slots(g.K), H1p, H2);
     const unsigned char* sb = reinterpret_cast<const unsigned char*>(saved);
     const unsigned int* words = reinterpret_cast<const unsigned int*>(sb + L.off_words);
@@ -667,7 +690,7 @@ int edge_dw2_slabs(int mode, int N, int K, int H1p, int H2) {
 }
 
 template <typename T>
-static hipError_t edge_dw2_t(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
+static hipError_t edge_dw2_t(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout,
                              long long ldg, const unsigned int* maskbits, long long row_begin, long long rows,
                              float* slab, float* db2_part, int splits, hipStream_t st) {
     const int S_ = edge_slots(g.K);
@@ -676,13 +699,13 @@ static hipError_t edge_dw2_t(const EdgeGraph& g, const void* PQ, int H1p, int H1
     const int n2t = cdiv__(H2, 128), kt = cdiv__(H1, 128);
     GN_DISPATCH_S(S_, {
         hipLaunchKernelGGL((edge_dw2_kernel<T, S>), dim3(n2t * kt, splits), dim3(256), 0, st,
-                           g, (const T*)PQ, H1p, H1, H2, gout, ldg, maskbits, row_begin, rps, slab, db2_part, n2t);
+                           g, (const T*)PQ, H1p, H1, H2, (const T*)gout, ldg, maskbits, row_begin, rps, slab, db2_part, n2t);
     });
     return hipGetLastError();
 }
-hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
+hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout,
                            long long ldg, void* saved, float* slab, float* db2_part, hipStream_t st) {
-    if (g.N == 0) return hipErrorInvalidValue;
+    if (g.N == 0 || (ldg & (mode ? 7 : 3))) return hipErrorInvalidValue;
     const int S_ = edge_slots(g.K);
     const SavedLayout L = saved_layout(g.N, S_, H1p, H2);
     unsigned char* sb = reinterpret_cast<unsigned char*>(saved);
@@ -703,16 +726,17 @@ hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p
                               slab + (long long)parts * H2 * H1, db2_part + (long long)parts * H2, DW2_OVF_SPLITS, st);
 }
 
+// dQ is float in mode 0 and bf16 in mode 1 (like dpre)
 hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows, int N,
-                            float* dQ, long long ldq, hipStream_t st) {
+                            void* dQ, long long ldq, hipStream_t st) {
     if (N == 0) return hipSuccess;
-    if (H1p > 512 || (H1p & 7) || (ldq & 3)) return hipErrorInvalidValue;
+    if (H1p > 512 || (H1p & 7) || (ldq & (mode ? 7 : 3))) return hipErrorInvalidValue;
     if (mode == 0)
         hipLaunchKernelGGL((dq_gather_kernel<float>), dim3(cdiv__(N, 4)), dim3(256), 0, st, (const float*)dpre, H1p,
-                           rev_ptr, rev_rows, N, dQ, ldq);
+                           rev_ptr, rev_rows, N, (float*)dQ, ldq);
     else
         hipLaunchKernelGGL((dq_gather_kernel<__bf16>), dim3(cdiv__(N, 4)), dim3(256), 0, st, (const __bf16*)dpre, H1p,
-                           rev_ptr, rev_rows, N, dQ, ldq);
+                           rev_ptr, rev_rows, N, (__bf16*)dQ, ldq);
     return hipGetLastError();
 }
 

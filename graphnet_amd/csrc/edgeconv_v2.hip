@@ -105,13 +105,13 @@ __device__ __forceinline__ unsigned int nonzero_bits_bf16x8(u32x4 o) {
 template <int KSTEPS>
 __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
     EdgeGraph g, const __bf16* __restrict__ PQ, const __bf16* __restrict__ W2p, const float* __restrict__ b2,
-    int H2, float* __restrict__ out, long long ldo, unsigned char* __restrict__ maskB, int ntiles)
+    int H2, __bf16* __restrict__ out, long long ldo, float* __restrict__ coords, CoordCols ccols,
+    unsigned char* __restrict__ maskB, int ntiles)
 {
     constexpr int S = 8;
     constexpr int K = KSTEPS * 16;                 // = H1p
     constexpr int ROWB = K * 2 + 16;               // LDS row pitch: conflict-free ds_read_b128
     constexpr int CHUNKS = K / 8;
-    constexpr int CPT = (CHUNKS + 7) / 8;
     __shared__ __attribute__((aligned(16))) unsigned char As[2][V2_ROWS * ROWB];
     __shared__ int s_jc[2][V2_ROWS];
 
@@ -134,6 +134,12 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
     }
     const int col = wave * 32 + r;
     const float bias = (col < H2) ? b2[col] : 0.0f;
+    // does this lane's column feed the fp32 coordinate copy (next layer's k-NN)?
+    int coord_d = -1;
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+        if (coords && d < ccols.n && ccols.c[d] == col) coord_d = d;
+    const bool is_coord = coord_d >= 0;
 
     // the gather of a tile is split in two chunk windows (registers: 2 x 3 x 16 B in flight)
     constexpr int CH_A = (CHUNKS / 2 + 7) / 8 * 8 < CHUNKS ? (CHUNKS / 2 + 7) / 8 * 8 : CHUNKS;   // first window
@@ -251,11 +257,12 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    const long long centre = c0t + rb * 4 + 2 * h + cc;
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const long long centre = c0t + rb * 4 + 2 * h + c2;
                     if (centre < g.N) {
-                        out[centre * ldo + col] = st_sum[rb][cc];
-                        maskB[centre * H2 + col] = (unsigned char)(st_msk >> (8 * (2 * rb + cc)));
+                        out[centre * ldo + col] = (__bf16)st_sum[rb][c2];
+                        maskB[centre * H2 + col] = (unsigned char)(st_msk >> (8 * (2 * rb + c2)));
+                        if (is_coord) coords[centre * 8 + coord_d] = st_sum[rb][c2];
                     }
                 }
         }
@@ -278,7 +285,7 @@ __host__ __device__ constexpr int tr_pitch(int row_bytes) {
 template <int NB1, int NBH, int HALVES>   // H1p = 32 * NB1
 __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
     EdgeGraph g, const __bf16* __restrict__ PQ, int H1, int H2,
-    const float* __restrict__ gout, long long ldg, const unsigned char* __restrict__ maskB,
+    const __bf16* __restrict__ gout, long long ldg, const unsigned char* __restrict__ maskB,
     unsigned char* __restrict__ hbits, float* __restrict__ slab, float* __restrict__ db2_part, int ntiles)
 {
     constexpr int S = 8;
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
             const long long c__ = (long long)(tile_) * 8 + 2 * s + h;                                 \
             const bool ok__ = (tile_) < ntiles && c__ < g.N && n2 < H2;                               \
             const long long cs__ = ok__ ? c__ : 0;                                                    \
-            const float gl__ = gout[cs__ * ldg + n2c];                                                \
+            const float gl__ = (float)gout[cs__ * ldg + n2c];                                         \
             const unsigned int ml__ = maskB[cs__ * H2 + n2c];                                         \
             gv_[s] = ok__ ? gl__ : 0.0f;                                                              \
             (mv_) = ((mv_) << 8) | (ok__ ? ml__ : 0u);                                                \
@@ -440,9 +447,9 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
 // three SIMDs (VGPR budget 168): W2^T slice 64 + accumulators 32 + staging.  NB1 = 4 -> 8 waves.
 template <int NB1>   // H1p = 32 * NB1, H2 == 256
 __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
-    EdgeGraph g, const float* __restrict__ gout, long long ldg, const unsigned char* __restrict__ maskB,
+    EdgeGraph g, const __bf16* __restrict__ gout, long long ldg, const unsigned char* __restrict__ maskB,
     const unsigned char* __restrict__ hbits, const __bf16* __restrict__ W2Tp,
-    __bf16* __restrict__ dpre, float* __restrict__ dP, long long ldp, int ntiles)
+    __bf16* __restrict__ dpre, __bf16* __restrict__ dP, long long ldp, int ntiles)
 {
     constexpr int S = 8;
     constexpr int NT = (NB1 > 8 ? NB1 : 8) * 64;   // threads
@@ -475,7 +482,7 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
 
     // dm build mapping: wave = centre of the tile, lane&31 = 8-column chunk, lane>>5 = slot half
     const int bcl = wave & 7, bcc = lane & 31, bsh = lane >> 5;
-    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+    u32x4 gw = {0u, 0u, 0u, 0u};                    // 8 bf16 of g_out[centre], as stored
     unsigned int mlo = 0, mhi = 0;
     unsigned int hbw[HBW];
     bool dm_ok = false, hb_ok[HBW];
@@ -488,9 +495,7 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
             const long long c__ = (long long)(tile_) * 8 + bcl;                                       \
             dm_ok = (tile_) < ntiles && c__ < g.N;                                                    \
             const long long cs__ = dm_ok ? c__ : 0;                                                   \
-            const float* gp__ = gout + cs__ * ldg + bcc * 8;                                          \
-            g0 = *reinterpret_cast<const f32x4*>(gp__);                                               \
-            g1 = *reinterpret_cast<const f32x4*>(gp__ + 4);                                           \
+            gw = *reinterpret_cast<const u32x4*>(gout + cs__ * ldg + bcc * 8);                        \
             const unsigned int* mp__ = reinterpret_cast<const unsigned int*>(maskB + cs__ * K2 + bcc * 8); \
             mlo = mp__[0];                                                                            \
             mhi = mp__[1];                                                                            \
@@ -506,9 +511,7 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
 #define GN_V2_WRITE_DM(buf_)                                                                          \
     {                                                                                                 \
         if (builder) {                                                                                \
-            unsigned int gw__[4];                                                                     \
-            gw__[0] = pack_bf16x2(g0[0], g0[1]); gw__[1] = pack_bf16x2(g0[2], g0[3]);                 \
-            gw__[2] = pack_bf16x2(g1[0], g1[1]); gw__[3] = pack_bf16x2(g1[2], g1[3]);                 \
+            const u32x4 gw__ = gw;                                                                    \
             const unsigned int okm__ = dm_ok ? 0x01010101u : 0u;                                      \
             _Pragma("unroll") for (int si = 0; si < 4; ++si) {                                        \
                 const int slot__ = 4 * bsh + si;                                                      \
@@ -585,7 +588,7 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
                     }
                     sum += __shfl_xor(sum, 32);
                     const long long centre = c0t + rb * 4 + c;
-                    if ((c >> 1) == h && centre < g.N) dP[centre * ldp + col] = sum;
+                    if ((c >> 1) == h && centre < g.N) dP[centre * ldp + col] = (__bf16)sum;
                 }
             }
         }
@@ -624,17 +627,18 @@ bool edge_v2_shape_ok(int K, int H1p, int H2) {
 }
 
 hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
-                              float* out, long long ldo, unsigned char* maskB, int num_cus, hipStream_t st) {
+                              void* out, long long ldo, float* coords, const CoordCols& cc, unsigned char* maskB,
+                              int num_cus, hipStream_t st) {
     if (!edge_v2_shape_ok(g.K, H1p, H2)) return hipErrorNotSupported;
     if (g.N == 0) return hipSuccess;
     const int ntiles = v2_tiles(g);
     const int grid = ntiles < num_cus ? ntiles : num_cus;
     if (H1p == 128)
         hipLaunchKernelGGL((edge_fwd_v2_kernel<8>), dim3(grid), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
-                           (const __bf16*)W2p, b2, H2, out, ldo, maskB, ntiles);
+                           (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, coords, cc, maskB, ntiles);
     else
         hipLaunchKernelGGL((edge_fwd_v2_kernel<22>), dim3(grid), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
-                           (const __bf16*)W2p, b2, H2, out, ldo, maskB, ntiles);
+                           (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, coords, cc, maskB, ntiles);
     return hipGetLastError();
 }
 
@@ -648,7 +652,7 @@ int edge_dw2_v2_parts(int N, int H1p, int num_cus) {
 }
 
 // slab: [parts][H2][H1], db2_part: [parts][H2] with parts = edge_dw2_v2_parts()
-hipError_t launch_edge_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
+hipError_t launch_edge_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout,
                               long long ldg, const unsigned char* maskB, unsigned char* hbits, float* slab,
                               float* db2_part, int num_cus, hipStream_t st) {
     if (!edge_v2_shape_ok(g.K, H1p, H2)) return hipErrorNotSupported;
@@ -657,26 +661,26 @@ hipError_t launch_edge_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H
     const int parts = edge_dw2_v2_parts(g.N, H1p, num_cus);
     if (H1p == 128)
         hipLaunchKernelGGL((edge_dw2_v2_kernel<4, 4, 1>), dim3(parts), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
-                           H1, H2, gout, ldg, maskB, hbits, slab, db2_part, ntiles);
+                           H1, H2, (const __bf16*)gout, ldg, maskB, hbits, slab, db2_part, ntiles);
     else
         hipLaunchKernelGGL((edge_dw2_v2_kernel<11, 6, 2>), dim3(parts * 2), dim3(V2_THREADS), 0, st, g,
-                           (const __bf16*)PQ, H1, H2, gout, ldg, maskB, hbits, slab, db2_part, ntiles);
+                           (const __bf16*)PQ, H1, H2, (const __bf16*)gout, ldg, maskB, hbits, slab, db2_part, ntiles);
     return hipGetLastError();
 }
 
-hipError_t launch_edge_bwd_v2(const EdgeGraph& g, int H1p, int H2, const float* gout, long long ldg,
+hipError_t launch_edge_bwd_v2(const EdgeGraph& g, int H1p, int H2, const void* gout, long long ldg,
                               const unsigned char* maskB, const unsigned char* hbits, const void* W2Tp, int H2p,
-                              void* dpre, float* dP, long long ldp, int num_cus, hipStream_t st) {
+                              void* dpre, void* dP, long long ldp, int num_cus, hipStream_t st) {
     if (!edge_v2_shape_ok(g.K, H1p, H2) || H2p != 256) return hipErrorNotSupported;
     if (g.N == 0) return hipSuccess;
     const int ntiles = v2_tiles(g);
     const int grid = ntiles < num_cus ? ntiles : num_cus;
     if (H1p == 128)
-        hipLaunchKernelGGL((edge_bwd_v2_kernel<4>), dim3(grid), dim3(512), 0, st, g, gout, ldg, maskB, hbits,
-                           (const __bf16*)W2Tp, (__bf16*)dpre, dP, ldp, ntiles);
+        hipLaunchKernelGGL((edge_bwd_v2_kernel<4>), dim3(grid), dim3(512), 0, st, g, (const __bf16*)gout, ldg, maskB, hbits,
+                           (const __bf16*)W2Tp, (__bf16*)dpre, (__bf16*)dP, ldp, ntiles);
     else
-        hipLaunchKernelGGL((edge_bwd_v2_kernel<11>), dim3(grid), dim3(704), 0, st, g, gout, ldg, maskB, hbits,
-                           (const __bf16*)W2Tp, (__bf16*)dpre, dP, ldp, ntiles);
+        hipLaunchKernelGGL((edge_bwd_v2_kernel<11>), dim3(grid), dim3(704), 0, st, g, (const __bf16*)gout, ldg, maskB, hbits,
+                           (const __bf16*)W2Tp, (__bf16*)dpre, (__bf16*)dP, ldp, ntiles);
     return hipGetLastError();
 }
 

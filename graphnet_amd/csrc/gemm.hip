@@ -19,14 +19,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <typename T, int BM, int BN, int BKE, typename OutT>
+template <typename T, int BM, int BN, int BKE, typename OutT, typename AT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __restrict__ Wp, int Kp, int Nreal,
                                                       Epi epi, OutT* __restrict__ C, long long ldc, int ntn) {
+    static_assert(sizeof(AT) == 4 || sizeof(T) == 2, "bf16 A rows need the bf16 compute type");
     constexpr int ROWB = BKE * (int)sizeof(T) + 16;            // padded LDS row pitch
     constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int ACOLT = BKE / 4;                             // threads covering one A row (float4 each)
+    constexpr int AEL = 16 / (int)sizeof(AT);                  // A elements per 16-byte load
+    constexpr int ACOLT = BKE / AEL;                           // threads covering one A row (16 bytes each)
     constexpr int AROWS = 256 / ACOLT;                         // A rows covered per pass
-    constexpr int ACH = BM / AROWS;                            // float4 loads of A per thread
+    constexpr int ACH = BM / AROWS;                            // 16-byte loads of A per thread
     constexpr int BCHROW = BKE * (int)sizeof(T) / 16;          // 16-byte chunks per W row
     constexpr int BCH = BN * BCHROW / 256;
     __shared__ __attribute__((aligned(16))) unsigned char As[BM * ROWB];
@@ -44,12 +46,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __
 #pragma unroll
         for (int j = 0; j < TN; ++j) zero_acc(acc[i][j]);
 
-    const int c4 = (tid % ACOLT) * 4, r0 = tid / ACOLT;
-    float4 areg[ACH];
+    const int c4 = (tid % ACOLT) * AEL, r0 = tid / ACOLT;
+    u32x4 areg[ACH];
     u32x4 breg[BCH];
 
     int seg = 0, kin = 0, kglob = 0;   // current block: segment, offset inside it, offset in Kp
-    const float* ap = a.p[0];
+    const AT* ap = reinterpret_cast<const AT*>(a.p[0]);
     long long ald = a.ld[0];
     int awidth = a.width[0], akpad = a.kpad[0];
 #define GN_GEMM_LOAD_REGS()                                                                              \
@@ -58,8 +60,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __
         _Pragma("unroll") for (int i = 0; i < ACH; ++i) {                                                \
             const int row = m0 + r0 + AROWS * i;                                                         \
             areg[i] = (colok && row < M)                                                                 \
-                          ? *reinterpret_cast<const float4*>(ap + (long long)row * ald + kin + c4)       \
-                          : make_float4(0.f, 0.f, 0.f, 0.f);                                             \
+                          ? *reinterpret_cast<const u32x4*>(ap + (long long)row * ald + kin + c4)        \
+                          : (u32x4){0u, 0u, 0u, 0u};                                                     \
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < BCH; ++i) {                                                \
             const int ch = tid + 256 * i;                                                                \
@@ -74,8 +76,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __
     for (int kb = 0; kb < nkb; ++kb) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < ACH; ++i)
-            store4<T>(As + (r0 + AROWS * i) * ROWB + c4 * sizeof(T), areg[i].x, areg[i].y, areg[i].z, areg[i].w);
+        for (int i = 0; i < ACH; ++i) {
+            unsigned char* dst = As + (r0 + AROWS * i) * ROWB + c4 * sizeof(T);
+            if constexpr (sizeof(AT) == 4) {
+                const f32x4 v = __builtin_bit_cast(f32x4, areg[i]);
+                store4<T>(dst, v[0], v[1], v[2], v[3]);
+            } else {
+                *reinterpret_cast<u32x4*>(dst) = areg[i];      // bf16 rows go to LDS as they are
+            }
+        }
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             const int ch = tid + 256 * i;
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __
                 kin = 0; ++seg;
 #pragma unroll
                 for (int s = 1; s < MAXSEG; ++s)   // static indexing keeps the arg struct out of scratch
-                    if (s == seg) { ap = a.p[s]; ald = a.ld[s]; awidth = a.width[s]; akpad = a.kpad[s]; }
+                    if (s == seg) { ap = reinterpret_cast<const AT*>(a.p[s]); ald = a.ld[s]; awidth = a.width[s]; akpad = a.kpad[s]; }
             }
             GN_GEMM_LOAD_REGS();
         }
@@ -132,14 +141,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Segs a, int M, const T* __
                 const int row = rowb + i * 32 + acc_row(r, 0);
                 if (row >= M) continue;
                 float v = fmaxf(acc[i][j][r] + b, lo);
-                if (epi.gate && !(epi.gate[(long long)row * epi.ldgate + col] > 0.0f)) v = 0.0f;
-                OutT* dst = C + (long long)row * ldc + col;
-                if constexpr (sizeof(OutT) == 4) {
-                    if (epi.accum) v += *dst;
-                    *dst = v;
-                } else {
-                    *dst = from_f32<OutT>(v);
+                if (epi.gate) {
+                    const long long gi = (long long)row * epi.ldgate + col;
+                    const float gv = epi.gate_lowp ? (float)reinterpret_cast<const __bf16*>(epi.gate)[gi]
+                                                   : reinterpret_cast<const float*>(epi.gate)[gi];
+                    if (!(gv > 0.0f)) v = 0.0f;
                 }
+                OutT* dst = C + (long long)row * ldc + col;
+                if (epi.accum) v += to_f32(*dst);
+                *dst = from_f32<OutT>(v);
             }
         }
 }
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     for (int s = 0; s < MAXSEG; ++s) {
         if (s < x.nseg && !found) {
             const int nt = (x.width[s] + BT - 1) / BT;
-            if (tk < nt) { kcol0 = tk * BT; xp = x.p[s]; ldx = x.ld[s]; xw = x.width[s]; found = true; }
+            if (tk < nt) { kcol0 = tk * BT; xp = reinterpret_cast<const float*>(x.p[s]); ldx = x.ld[s]; xw = x.width[s]; found = true; }
             else { tk -= nt; kout0 += x.width[s]; }
         }
     }
@@ -253,9 +263,35 @@ __device__ __forceinline__ unsigned int pk_bf16(float lo, float hi) {
 }
 __host__ __device__ constexpr int tr_pitch_g(int row_bytes) { return row_bytes + ((64 - row_bytes % 256) + 256) % 256; }
 
+// 8 consecutive row elements in flight between global memory and the bf16 LDS tile
+template <typename E> struct Chunk8;
+template <> struct Chunk8<float> { f32x4 a, b; };
+template <> struct Chunk8<__bf16> { u32x4 w; };
+// branch-free: out-of-range pieces are read from a clamped (valid) address and zeroed
+__device__ __forceinline__ void load_chunk8(Chunk8<float>& r, const float* row, int c, int lim, bool rok) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(row + (c < lim ? c : 0));
+    const f32x4 b = *reinterpret_cast<const f32x4*>(row + (c + 4 < lim ? c + 4 : 0));
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    r.a = (rok && c < lim) ? a : z;
+    r.b = (rok && c + 4 < lim) ? b : z;
+}
+__device__ __forceinline__ void load_chunk8(Chunk8<__bf16>& r, const __bf16* row, int c, int lim, bool rok) {
+    const u32x4 w = *reinterpret_cast<const u32x4*>(row + (c < lim ? c : 0));      // lim % 8 == 0
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    r.w = (rok && c < lim) ? w : z;
+}
+__device__ __forceinline__ u32x4 pack_chunk8(const Chunk8<float>& r) {
+    u32x4 w;
+    w[0] = pk_bf16(r.a[0], r.a[1]); w[1] = pk_bf16(r.a[2], r.a[3]);
+    w[2] = pk_bf16(r.b[0], r.b[1]); w[3] = pk_bf16(r.b[2], r.b[3]);
+    return w;
+}
+__device__ __forceinline__ u32x4 pack_chunk8(const Chunk8<__bf16>& r) { return r.w; }
+
 constexpr int TN2_ROWS = 64, TN2_N1 = 256, TN2_K = 128;
+template <typename DYT, typename XT>
 __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
-    const float* __restrict__ dY, long long lddy, int N1, Segs x, int M, int nparts,
+    const DYT* __restrict__ dY, long long lddy, int N1, Segs x, int M, int nparts,
     float* __restrict__ slab, float* __restrict__ db_part, int Ktot, int n1_tiles, int k_tiles)
 {
     constexpr int YP = tr_pitch_g(TN2_N1 * 2);      // 576
@@ -270,14 +306,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
     int tk = ((int)blockIdx.x / n1_tiles) % k_tiles;
     const int part = (int)blockIdx.x / (n1_tiles * k_tiles);
     int kcol0 = 0, kout0 = 0, xw = 0;
-    const float* xp = nullptr;
+    const XT* xp = nullptr;
     long long ldx = 0;
     bool found = false, first_k = (tk == 0);
 #pragma unroll
     for (int s = 0; s < MAXSEG; ++s) {
         if (s < x.nseg && !found) {
             const int nt = (x.width[s] + TN2_K - 1) / TN2_K;
-            if (tk < nt) { kcol0 = tk * TN2_K; xp = x.p[s]; ldx = x.ld[s]; xw = x.width[s]; found = true; }
+            if (tk < nt) { kcol0 = tk * TN2_K; xp = reinterpret_cast<const XT*>(x.p[s]); ldx = x.ld[s]; xw = x.width[s]; found = true; }
             else { tk -= nt; kout0 += x.width[s]; }
         }
     }
@@ -295,45 +331,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
 
     // staging: 8 threads per row; thread handles 16-byte bf16 chunks (tid&7)+8j (8 columns each)
     const int srow = tid >> 3, sc = tid & 7;
-    f32x4 yr[4][2], xr[2][2];
+    Chunk8<DYT> yr[4];
+    Chunk8<XT> xr[2];
 #define GN_TN2_LOAD(t_)                                                                              \
     {                                                                                                \
         const int m__ = (t_) * TN2_ROWS + srow;                                                      \
         const bool mok__ = (t_) < tile_end && m__ < M;                                               \
         const long long ms__ = mok__ ? m__ : 0;                                                      \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
-            const int c__ = n1_0 + (sc + 8 * j) * 8;                                                 \
-            const float* p__ = dY + ms__ * lddy;                                                     \
-            const f32x4 a__ = *reinterpret_cast<const f32x4*>(p__ + (c__ < N1 ? c__ : 0));          \
-            const f32x4 b__ = *reinterpret_cast<const f32x4*>(p__ + (c__ + 4 < N1 ? c__ + 4 : 0));  \
-            const f32x4 z__ = {0.f, 0.f, 0.f, 0.f};                                                  \
-            yr[j][0] = (mok__ && c__ < N1) ? a__ : z__;                                              \
-            yr[j][1] = (mok__ && c__ + 4 < N1) ? b__ : z__;                                          \
-        }                                                                                            \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
-            const int c__ = kcol0 + (sc + 8 * j) * 8;                                                \
-            const float* p__ = xp + ms__ * ldx;                                                      \
-            const f32x4 a__ = *reinterpret_cast<const f32x4*>(p__ + (c__ < xw ? c__ : 0));           \
-            const f32x4 b__ = *reinterpret_cast<const f32x4*>(p__ + (c__ + 4 < xw ? c__ + 4 : 0));   \
-            const f32x4 z__ = {0.f, 0.f, 0.f, 0.f};                                                  \
-            xr[j][0] = (mok__ && c__ < xw) ? a__ : z__;                                              \
-            xr[j][1] = (mok__ && c__ + 4 < xw) ? b__ : z__;                                          \
-        }                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
+            load_chunk8(yr[j], dY + ms__ * lddy, n1_0 + (sc + 8 * j) * 8, N1, mok__);                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+            load_chunk8(xr[j], xp + ms__ * ldx, kcol0 + (sc + 8 * j) * 8, xw, mok__);                \
     }
 #define GN_TN2_WRITE(buf_)                                                                           \
     {                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
-            u32x4 w__;                                                                               \
-            w__[0] = pk_bf16(yr[j][0][0], yr[j][0][1]); w__[1] = pk_bf16(yr[j][0][2], yr[j][0][3]);  \
-            w__[2] = pk_bf16(yr[j][1][0], yr[j][1][1]); w__[3] = pk_bf16(yr[j][1][2], yr[j][1][3]);  \
-            *reinterpret_cast<u32x4*>(&Ys[buf_][srow * YP + (sc + 8 * j) * 16]) = w__;               \
-        }                                                                                            \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
-            u32x4 w__;                                                                               \
-            w__[0] = pk_bf16(xr[j][0][0], xr[j][0][1]); w__[1] = pk_bf16(xr[j][0][2], xr[j][0][3]);  \
-            w__[2] = pk_bf16(xr[j][1][0], xr[j][1][1]); w__[3] = pk_bf16(xr[j][1][2], xr[j][1][3]);  \
-            *reinterpret_cast<u32x4*>(&Xs[buf_][srow * XP + (sc + 8 * j) * 16]) = w__;               \
-        }                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
+            *reinterpret_cast<u32x4*>(&Ys[buf_][srow * YP + (sc + 8 * j) * 16]) = pack_chunk8(yr[j]); \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+            *reinterpret_cast<u32x4*>(&Xs[buf_][srow * XP + (sc + 8 * j) * 16]) = pack_chunk8(xr[j]); \
     }
     // out-of-range float4s are read from a clamped (valid) address and zeroed: branch-free staging
 
@@ -458,19 +473,19 @@ static inline int cdiv_(long long a, long long b) { return (int)((a + b - 1) / b
 
 int device_cus();
 
-template <typename T, int BN, int BKE, typename OutT>
+template <typename T, int BN, int BKE, typename OutT, typename AT>
 static hipError_t launch_gemm_nt_cfg(const Segs& a, int M, const void* Wp, int Kp, int Npad, int Nreal, const Epi& epi,
                                      void* C, long long ldc, hipStream_t st) {
     constexpr int BM = 128;
     const int ntn = cdiv_(Nreal, BN);
     if (ntn * BN > Npad) return hipErrorInvalidValue;
     const int ntm = cdiv_(M, BM);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, BKE, OutT>), dim3(ntm * ntn), dim3(256), 0, st, a, M,
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, BKE, OutT, AT>), dim3(ntm * ntn), dim3(256), 0, st, a, M,
                        reinterpret_cast<const T*>(Wp), Kp, Nreal, epi, reinterpret_cast<OutT*>(C), ldc, ntn);
     return hipGetLastError();
 }
 
-template <typename T, typename OutT>
+template <typename T, typename OutT, typename AT>
 static hipError_t launch_gemm_nt_t(const Segs& a, int M, const void* Wp, int Kp, int Npad, int Nreal, const Epi& epi,
                                    void* C, long long ldc, hipStream_t st) {
     if (M == 0) return hipSuccess;
@@ -483,24 +498,33 @@ static hipError_t launch_gemm_nt_t(const Segs& a, int M, const void* Wp, int Kp,
         static const bool allow_k64 = !(getenv("GN_GEMM_K64") && getenv("GN_GEMM_K64")[0] == '0');
         k64 = k64 && allow_k64;
         const bool wide = allow_wide && cdiv_(Nreal, 256) * 256 <= cdiv_(Nreal, 128) * 128 && cdiv_(Nreal, 256) * 256 <= Npad;
-        if (k64 && wide) return launch_gemm_nt_cfg<T, 256, 64, OutT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
-        if (k64) return launch_gemm_nt_cfg<T, 128, 64, OutT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+        if (k64 && wide) return launch_gemm_nt_cfg<T, 256, 64, OutT, AT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+        if (k64) return launch_gemm_nt_cfg<T, 128, 64, OutT, AT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
     }
-    return launch_gemm_nt_cfg<T, 128, 32, OutT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+    return launch_gemm_nt_cfg<T, 128, 32, OutT, AT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
 }
 
-// mode: 0 = f32 operands, 1 = bf16 operands.  out_lowp: write C in the operand type.
-hipError_t launch_gemm_nt(int mode, const Segs& a, int M, const void* Wp, int Kp, int Npad, int Nreal, const Epi& epi,
-                          void* C, long long ldc, int out_lowp, hipStream_t st) {
+// mode: 0 = f32 MFMA, 1 = bf16 MFMA.  a_lowp: the A segments are bf16 rows (mode 1 only).
+// out_lowp: C is bf16 (mode 1 only).
+hipError_t launch_gemm_nt(int mode, const Segs& a, int a_lowp, int M, const void* Wp, int Kp, int Npad, int Nreal,
+                          const Epi& epi, void* C, long long ldc, int out_lowp, hipStream_t st) {
     int ksum = 0;
+    const int amask = a_lowp ? 7 : 3;                 // 16-byte loads: 8 bf16 / 4 floats
     for (int s = 0; s < a.nseg; ++s) {
-        if (a.kpad[s] % BK || a.width[s] > a.kpad[s] || (a.width[s] & 3) || (a.ld[s] & 3)) return hipErrorInvalidValue;
+        if (a.kpad[s] % BK || a.width[s] > a.kpad[s] || (a.width[s] & amask) || (a.ld[s] & amask)) return hipErrorInvalidValue;
         ksum += a.kpad[s];
     }
     if (ksum != Kp) return hipErrorInvalidValue;
-    if (mode == 0) return launch_gemm_nt_t<float, float>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
-    if (out_lowp) return launch_gemm_nt_t<__bf16, __bf16>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
-    return launch_gemm_nt_t<__bf16, float>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+    if (mode == 0) {
+        if (a_lowp || out_lowp || epi.gate_lowp) return hipErrorInvalidValue;
+        return launch_gemm_nt_t<float, float, float>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+    }
+    if (a_lowp) {
+        if (out_lowp) return launch_gemm_nt_t<__bf16, __bf16, __bf16>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+        return launch_gemm_nt_t<__bf16, float, __bf16>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+    }
+    if (out_lowp) return launch_gemm_nt_t<__bf16, __bf16, float>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
+    return launch_gemm_nt_t<__bf16, float, float>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
 }
 
 // splits over the contraction (rows): aim at ~1024 workgroups in total, at least 512 rows per split
@@ -534,22 +558,36 @@ int gemm_tn_parts(int mode, int M, int N1, const int* widths, int nseg) {
 
 // dW[N1, Ktot] (+)= dY^T . [X_seg0 | X_seg1 | ...];  db[N1] (+)= colsum(dY) when db != null.
 // slab: >= parts*N1*Ktot floats, db_part: >= parts*N1 floats (parts = gemm_tn_parts()).
-hipError_t launch_gemm_tn(int mode, const float* dY, long long lddy, int N1, const Segs& x, int M, float* slab,
-                          float* db_part, float* dW, float* db, int accum, hipStream_t st) {
+hipError_t launch_gemm_tn(int mode, const void* dY, int dy_lowp, long long lddy, int N1, const Segs& x, int x_lowp,
+                          int M, float* slab, float* db_part, float* dW, float* db, int accum, hipStream_t st) {
     int Ktot = 0, ktiles = 0, ktiles2 = 0;
+    const int xmask = x_lowp ? 7 : 3, ymask = dy_lowp ? 7 : 3;      // 16-byte row pieces
     for (int s = 0; s < x.nseg; ++s) {
-        if ((x.width[s] & 3) || (x.ld[s] & 3)) return hipErrorInvalidValue;
+        if ((x.width[s] & xmask) || (x.ld[s] & xmask)) return hipErrorInvalidValue;
         Ktot += x.width[s];
         ktiles += cdiv_(x.width[s], 128);
         ktiles2 += cdiv_(x.width[s], TN2_K);
     }
-    if ((lddy & 3) || (N1 & 3)) return hipErrorInvalidValue;
+    if ((lddy & ymask) || (N1 & ymask)) return hipErrorInvalidValue;
+    if (mode == 0 && (dy_lowp || x_lowp)) return hipErrorInvalidValue;
     const long long count = (long long)N1 * Ktot;
     if (mode == 1) {
         const int parts = gemm_tn_parts(mode, M, N1, x.width, x.nseg);
         const int n1t = cdiv_(N1, TN2_N1);
-        hipLaunchKernelGGL(gemm_tn_v2_kernel, dim3(n1t * ktiles2 * parts), dim3(512), 0, st, dY, lddy, N1, x, M, parts,
-                           slab, db ? db_part : nullptr, Ktot, n1t, ktiles2);
+        const dim3 grid(n1t * ktiles2 * parts), block(512);
+        float* dbp = db ? db_part : nullptr;
+        if (dy_lowp && x_lowp)
+            hipLaunchKernelGGL((gemm_tn_v2_kernel<__bf16, __bf16>), grid, block, 0, st, (const __bf16*)dY, lddy, N1, x, M,
+                               parts, slab, dbp, Ktot, n1t, ktiles2);
+        else if (dy_lowp)
+            hipLaunchKernelGGL((gemm_tn_v2_kernel<__bf16, float>), grid, block, 0, st, (const __bf16*)dY, lddy, N1, x, M,
+                               parts, slab, dbp, Ktot, n1t, ktiles2);
+        else if (x_lowp)
+            hipLaunchKernelGGL((gemm_tn_v2_kernel<float, __bf16>), grid, block, 0, st, (const float*)dY, lddy, N1, x, M,
+                               parts, slab, dbp, Ktot, n1t, ktiles2);
+        else
+            hipLaunchKernelGGL((gemm_tn_v2_kernel<float, float>), grid, block, 0, st, (const float*)dY, lddy, N1, x, M,
+                               parts, slab, dbp, Ktot, n1t, ktiles2);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(count, 256)), dim3(256), 0, st, slab, parts, count, dW, accum);
         if (db)
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(N1, 256)), dim3(256), 0, st, db_part, parts, (long long)N1,
@@ -561,10 +599,10 @@ hipError_t launch_gemm_tn(int mode, const float* dY, long long lddy, int N1, con
     rps = cdiv_(rps, BK) * BK;
     const int n1t = cdiv_(N1, 128);
     dim3 grid(n1t * ktiles, splits);
-    hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, st, dY, lddy, N1, x, M, rps, slab, Ktot, n1t);
+    hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, st, (const float*)dY, lddy, N1, x, M, rps, slab, Ktot, n1t);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(count, 256)), dim3(256), 0, st, slab, splits, count, dW, accum);
     if (db) {                                          // f32 mode: separate column-sum pass
-        hipError_t e = launch_colsum(dY, lddy, M, N1, db_part, db, accum, st);
+        hipError_t e = launch_colsum((const float*)dY, lddy, M, N1, db_part, db, accum, st);
         if (e != hipSuccess) return e;
     }
     return hipGetLastError();

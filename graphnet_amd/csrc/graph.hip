@@ -358,17 +358,18 @@ __global__ __launch_bounds__(256) void globals_kernel(
 }
 
 // x0[i, 0:F] = x[i,:], x0[i, F:F+G] = gv[batch[i], :], zero padding up to ld0 columns.
+template <typename OutT>
 __global__ __launch_bounds__(256) void concat_globals(const float* __restrict__ x, long long ldx, int F,
                                                       const float* __restrict__ gv, int G,
                                                       const int* __restrict__ batch, int N,
-                                                      float* __restrict__ x0, int ld0) {
+                                                      OutT* __restrict__ x0, int ld0) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int i = (int)(t / ld0), c = (int)(t % ld0);
     if (i >= N) return;
     float v = 0.0f;
     if (c < F) v = x[(long long)i * ldx + c];
     else if (c < F + G) v = gv[(long long)batch[i] * G + (c - F)];
-    x0[(long long)i * ld0 + c] = v;
+    x0[(long long)i * ld0 + c] = from_f32<OutT>(v);
 }
 
 __global__ __launch_bounds__(256) void ptr_to_batch(const int* __restrict__ ptr, int B, int* __restrict__ batch) {
@@ -469,9 +470,13 @@ hipError_t launch_globals(const float* x, long long ldx, int F, const int* ptr, 
     return hipGetLastError();
 }
 hipError_t launch_concat_globals(const float* x, long long ldx, int F, const float* gv, int G, const int* batch, int N,
-                                 float* x0, int ld0, hipStream_t st) {
+                                 void* x0, int ld0, int out_lowp, hipStream_t st) {
     if (N == 0) return hipSuccess;
-    hipLaunchKernelGGL(concat_globals, dim3(cdiv((long long)N * ld0, 256)), dim3(256), 0, st, x, ldx, F, gv, G, batch, N, x0, ld0);
+    const dim3 grid(cdiv((long long)N * ld0, 256)), block(256);
+    if (out_lowp)
+        hipLaunchKernelGGL(concat_globals<__bf16>, grid, block, 0, st, x, ldx, F, gv, G, batch, N, (__bf16*)x0, ld0);
+    else
+        hipLaunchKernelGGL(concat_globals<float>, grid, block, 0, st, x, ldx, F, gv, G, batch, N, (float*)x0, ld0);
     return hipGetLastError();
 }
 hipError_t launch_ptr_to_batch(const int* ptr, int B, int* batch, hipStream_t st) {

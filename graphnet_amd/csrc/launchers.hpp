@@ -20,14 +20,14 @@ hipError_t launch_edges_to_table(const long long* edge_index, long long E, int N
 hipError_t launch_globals(const float* x, long long ldx, int F, const int* ptr, int B, const int* nbr, const int* ovf,
                           int K, const int* n_pulses, float* out, hipStream_t st);
 hipError_t launch_concat_globals(const float* x, long long ldx, int F, const float* gv, int G, const int* batch, int N,
-                                 float* x0, int ld0, hipStream_t st);
+                                 void* x0, int ld0, int out_lowp, hipStream_t st);
 hipError_t launch_ptr_to_batch(const int* ptr, int B, int* batch, hipStream_t st);
 // gemm.hip
-hipError_t launch_gemm_nt(int mode, const Segs& a, int M, const void* Wp, int Kp, int Npad, int Nreal, const Epi& epi,
-                          void* C, long long ldc, int out_lowp, hipStream_t st);
+hipError_t launch_gemm_nt(int mode, const Segs& a, int a_lowp, int M, const void* Wp, int Kp, int Npad, int Nreal,
+                          const Epi& epi, void* C, long long ldc, int out_lowp, hipStream_t st);
 int gemm_tn_parts(int mode, int M, int N1, const int* widths, int nseg);
-hipError_t launch_gemm_tn(int mode, const float* dY, long long lddy, int N1, const Segs& x, int M, float* slab,
-                          float* db_part, float* dW, float* db, int accum, hipStream_t st);
+hipError_t launch_gemm_tn(int mode, const void* dY, int dy_lowp, long long lddy, int N1, const Segs& x, int x_lowp,
+                          int M, float* slab, float* db_part, float* dW, float* db, int accum, hipStream_t st);
 int colsum_blocks(int M);
 hipError_t launch_colsum(const float* X, long long ld, int M, int C, float* part, float* out, int accum, hipStream_t st);
 hipError_t launch_reduce_slabs(const float* slab, int nslab, long long count, float* out, int accum, hipStream_t st);
@@ -35,19 +35,20 @@ hipError_t launch_reduce_slabs(const float* slab, int nslab, long long count, fl
 int edge_slots(int K);
 long long edge_dw2_splits(long long rows);
 hipError_t launch_edge_fwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2,
-                           int H2, float* out, long long ldo, void* saved, hipStream_t st);
-hipError_t launch_edge_bwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H2, const float* gout,
+                           int H2, void* out, long long ldo, float* coords, const int* coord_cols, int ncoord,
+                           void* saved, hipStream_t st);
+hipError_t launch_edge_bwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H2, const void* gout,
                            long long ldg, const void* saved, const void* W2Tp, int H2p, void* dpre,
-                           float* dP, long long ldp, hipStream_t st);
+                           void* dP, long long ldp, hipStream_t st);
 int edge_dw2_slabs(int mode, int N, int K, int H1p, int H2);
-hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const float* gout,
+hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout,
                            long long ldg, void* saved, float* slab, float* db2_part, hipStream_t st);
 hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows, int N,
-                            float* dQ, long long ldq, hipStream_t st);
+                            void* dQ, long long ldq, hipStream_t st);
 // pool.hip
 hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr, int B, const int* codes, int ns,
                            float* out, int* argmin, int* argmax, hipStream_t st);
 hipError_t launch_pool_bwd(const float* gout, int C, const int* ptr, const int* batch, int N, const int* codes, int ns,
-                           const int* argmin, const int* argmax, const float* gate, long long ldgate, float* dx,
-                           long long lddx, hipStream_t st);
+                           const int* argmin, const int* argmax, const float* gate, long long ldgate, void* dx,
+                           long long lddx, int dx_lowp, hipStream_t st);
 }  // namespace gn

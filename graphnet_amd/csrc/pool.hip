@@ -59,10 +59,11 @@ __global__ __launch_bounds__(256) void segment_pool_fwd_kernel(
 }
 
 // dx[i][c] = gate(i,c) * ( g_sum + g_mean / n + [i == argmin] g_min + [i == argmax] g_max )
+template <typename OutT>
 __global__ __launch_bounds__(256) void segment_pool_bwd_kernel(
     const float* __restrict__ gout /*[B, n*C]*/, int C, const int* __restrict__ ptr, const int* __restrict__ batch,
     int N, PoolSchemes sch, const int* __restrict__ argmin, const int* __restrict__ argmax,
-    const float* __restrict__ gate, long long ldgate, float* __restrict__ dx, long long lddx)
+    const float* __restrict__ gate, long long ldgate, OutT* __restrict__ dx, long long lddx)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int i = (int)(t / C), c = (int)(t % C);
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void segment_pool_bwd_kernel(
         }
     }
     if (gate && !(gate[(long long)i * ldgate + c] > 0.0f)) v = 0.0f;
-    dx[(long long)i * lddx + c] = v;
+    dx[(long long)i * lddx + c] = from_f32<OutT>(v);
 }
 
 hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr, int B, const int* codes, int ns,
@@ -97,16 +98,21 @@ hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr,
 }
 
 hipError_t launch_pool_bwd(const float* gout, int C, const int* ptr, const int* batch, int N, const int* codes, int ns,
-                           const int* argmin, const int* argmax, const float* gate, long long ldgate, float* dx,
-                           long long lddx, hipStream_t st) {
+                           const int* argmin, const int* argmax, const float* gate, long long ldgate, void* dx,
+                           long long lddx, int dx_lowp, hipStream_t st) {
     if (N == 0) return hipSuccess;
     if (ns < 1 || ns > 4) return hipErrorInvalidValue;
     PoolSchemes s;
     s.n = ns;
     for (int i = 0; i < 4; ++i) s.code[i] = i < ns ? codes[i] : 0;
     const long long total = (long long)N * C;
-    hipLaunchKernelGGL(segment_pool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gout, C, ptr,
-                       batch, N, s, argmin, argmax, gate, ldgate, dx, lddx);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (dx_lowp)
+        hipLaunchKernelGGL(segment_pool_bwd_kernel<__bf16>, grid, block, 0, st, gout, C, ptr, batch, N, s, argmin, argmax,
+                           gate, ldgate, (__bf16*)dx, lddx);
+    else
+        hipLaunchKernelGGL(segment_pool_bwd_kernel<float>, grid, block, 0, st, gout, C, ptr, batch, N, s, argmin, argmax,
+                           gate, ldgate, (float*)dx, lddx);
     return hipGetLastError();
 }
 

@@ -64,23 +64,23 @@ def _subset_cols(subset: Union[slice, Sequence[int]], width: int) -> List[int]:
     return [int(c) for c in subset]
 
 
-def _kw(w: int) -> int:
-    """Kernel-side width of a segment: float4 granularity (the pad columns hold zeros)."""
-    return ops.round_up(w, 4)
+def _kw(w: int, unit: int = 4) -> int:
+    """Kernel-side width of a segment: one 16-byte load (4 floats / 8 bf16); the pad columns hold zeros."""
+    return ops.round_up(w, unit)
 
 
 def _ksegs(segs: Sequence[Tuple[Tensor, int]]) -> List[Tuple[Tensor, int]]:
-    return [(t, _kw(w)) for t, w in segs]
+    return [(t, _kw(w, ops.seg_unit(t.dtype))) for t, w in segs]
 
 
-def _unpad_cols(dW: Tensor, widths: Sequence[int]) -> Tensor:
-    """Drop the float4 pad columns of each segment from a weight gradient."""
-    if all(w == _kw(w) for w in widths):
+def _unpad_cols(dW: Tensor, widths: Sequence[int], unit: int = 4) -> Tensor:
+    """Drop the pad columns of each segment from a weight gradient."""
+    if all(w == _kw(w, unit) for w in widths):
         return dW
     parts, off = [], 0
     for w in widths:
         parts.append(dW[:, off: off + w])
-        off += _kw(w)
+        off += _kw(w, unit)
     return torch.cat(parts, dim=1)
 
 
@@ -105,9 +105,11 @@ class _DynEdgeFunction(torch.autograd.Function):
         gv = cfg["globals"]
         G = 0 if (gv is None or cfg["globals_after"]) else int(gv.shape[1])
         F0 = F + G
-        x0 = ops.concat_globals(x, gv if G else None, batch, ops.round_up(F0, 32))
+        act = ops.act_dtype(mode)                  # activations between kernels: fp32 / bf16 by mode
+        x0 = ops.concat_globals(x, gv if G else None, batch, ops.round_up(F0, 32), dtype=act)
         xs: List[Tuple[Tensor, int]] = [(x0, F0)]
         graphs, PQs, masks = [], [], []
+        knn_coords: List[Tensor] = []          # fp32 coordinates each re-built graph was computed from
         plan = None
         for l, (W1, b1, W2, b2) in enumerate(conv_p):
             xin, Fin = xs[-1]
@@ -119,32 +121,50 @@ class _DynEdgeFunction(torch.autograd.Function):
             Wpq[H1p:H1p + H1] = Wb
             bpq = torch.zeros(2 * H1p, dtype=torch.float32, device=x.device)
             bpq[:H1] = b1
-            PQ = ops.linear_fwd(mode, [(xin, _kw(Fin))], ops.pack_weight(Wpq, [Fin], dt, ku), 2 * H1p, bias=bpq,
+            PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), ops.pack_weight(Wpq, [Fin], dt, ku), 2 * H1p, bias=bpq,
                                 out_lowp=lowp)
-            out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, ops.pack_weight(W2, [H1], dt), b2.contiguous(), H2)
-            graphs.append(g); PQs.append(PQ); masks.append(mask)
-            xs.append((out, H2))
+            W2p = ops.pack_weight(W2, [H1], dt)
             if l + 1 < nconv:
+                cols = _subset_cols(cfg["features_subset"], H2)
                 if plan is None:
                     plan = ops.knn_plan(ptr)                  # query-tile plan: once per batch, all layers
-                g = ops.knn_graph(out, _subset_cols(cfg["features_subset"], H2), batch, ptr, cfg["k"],
-                                  strict=cfg["strict"], plan=plan)
+                if lowp and len(cols) <= 8:
+                    # bf16 activations: the k-NN coordinates leave the kernel as a separate fp32 copy
+                    out, mask, coords = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2.contiguous(), H2, coord_cols=cols)
+                    g_next = ops.knn_graph(coords, list(range(len(cols))), batch, ptr, cfg["k"],
+                                           strict=cfg["strict"], plan=plan)
+                    knn_coords.append(coords[:, :len(cols)])
+                else:
+                    out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2.contiguous(), H2)
+                    src = out.float() if lowp else out
+                    g_next = ops.knn_graph(src, cols, batch, ptr, cfg["k"], strict=cfg["strict"], plan=plan)
+                    knn_coords.append(src[:, cols])
+            else:
+                out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2.contiguous(), H2)
+                g_next = None
+            graphs.append(g); PQs.append(PQ); masks.append(mask)
+            xs.append((out, H2))
+            g = g_next
         ys: List[Tuple[Tensor, int]] = []
         segs = xs
-        for (W, b) in post_p:
+        for t, (W, b) in enumerate(post_p):
+            # hidden post-MLP layers are activations (bf16 in bf16 mode); the last one feeds pooling: fp32
             y = ops.linear_fwd(mode, _ksegs(segs), ops.pack_weight(W, [w for _, w in segs], dt, ku), int(W.shape[0]),
-                               bias=b.contiguous(), relu=True)
+                               bias=b.contiguous(), relu=True, out_lowp=lowp and t + 1 < npost,
+                               out_cols=ops.round_up(int(W.shape[0]), 8))
             ys.append((y, int(W.shape[0])))
             segs = [ys[-1]]
         y_last, P = ys[-1]
         ctx.cfg, ctx.xs, ctx.graphs, ctx.PQs, ctx.masks, ctx.ys = cfg, xs, graphs, PQs, masks, ys
         ctx.params = params
         ctx.amin = ctx.amax = None
-        cfg["trace"] = {"conv_out": [t for t, _ in xs], "graphs": graphs, "post": y_last} if cfg.get("want_trace") else None
+        cfg["trace"] = ({"conv_out": [t.float() for t, _ in xs], "graphs": graphs, "post": y_last[:, :P],
+                         "knn_coords": knn_coords}
+                        if cfg.get("want_trace") else None)
         if cfg["pools"]:
             pooled, ctx.amin, ctx.amax = ops.segment_pool_fwd(y_last, P, ptr, cfg["pools"])
             return pooled
-        return y_last
+        return y_last[:, :P] if int(y_last.shape[1]) != P else y_last
 
     @staticmethod
     def backward(ctx, gout: Tensor):  # type: ignore[override]
@@ -152,6 +172,7 @@ class _DynEdgeFunction(torch.autograd.Function):
         mode = cfg["mode"]
         dt = ops.mode_dtype(mode)
         ku = ops.gemm_kunit(mode)
+        lowp = mode == ops.MODE_BF16
         batch, ptr = cfg["batch"], cfg["ptr"]
         nconv, npost = cfg["nconv"], cfg["npost"]
         params = ctx.params
@@ -162,12 +183,14 @@ class _DynEdgeFunction(torch.autograd.Function):
         dev = xs[0][0].device
         grads: List[Optional[Tensor]] = [None] * len(params)
 
+        act = ops.act_dtype(mode)
+        unit = ops.seg_unit(act)
         y_last, P = ys[-1]
         gout = gout.contiguous().to(torch.float32)
         if cfg["pools"]:
-            dZ = ops.segment_pool_bwd(gout, P, ptr, batch, N, cfg["pools"], ctx.amin, ctx.amax, y_last)
+            dZ = ops.segment_pool_bwd(gout, P, ptr, batch, N, cfg["pools"], ctx.amin, ctx.amax, y_last, dtype=act)
         else:
-            dZ = gout * (y_last > 0)
+            dZ = (gout * (y_last[:, :P] > 0)).to(act).contiguous()
 
         # ---- post-processing MLP, last layer first
         seg_pad = [ops.round_up(w, 32) for _, w in xs]
@@ -178,18 +201,20 @@ class _DynEdgeFunction(torch.autograd.Function):
             Pt = int(W.shape[0])
             in_segs = xs if t == 0 else [ys[t - 1]]
             dWt, dbt = ops.linear_wgrad(mode, dZ, Pt, _ksegs(in_segs), with_bias=True)
-            grads[4 * nconv + 2 * t] = _unpad_cols(dWt, [w for _, w in in_segs])
+            grads[4 * nconv + 2 * t] = _unpad_cols(dWt, [w for _, w in in_segs], unit)
             grads[4 * nconv + 2 * t + 1] = dbt
             if t > 0:
                 yprev, Pprev = ys[t - 1]
-                dZ = ops.linear_fwd(mode, [(dZ, Pt)], ops.pack_weight(W.t(), [Pt], dt, ku), Pprev, gate=yprev)
+                dZ = ops.linear_fwd(mode, _ksegs([(dZ, Pt)]), ops.pack_weight(W.t(), [Pt], dt, ku), Pprev, gate=yprev,
+                                    out_lowp=lowp, out_cols=ops.round_up(Pprev, 8))
             else:
                 WT = torch.zeros((sum(seg_pad), Pt), dtype=torch.float32, device=dev)
                 off = 0
                 for s, (_, w) in enumerate(xs):
                     WT[seg_off[s]: seg_off[s] + w] = W[:, off: off + w].t()
                     off += w
-                dXcat = ops.linear_fwd(mode, [(dZ, Pt)], ops.pack_weight(WT, [Pt], dt, ku), sum(seg_pad))
+                dXcat = ops.linear_fwd(mode, _ksegs([(dZ, Pt)]), ops.pack_weight(WT, [Pt], dt, ku), sum(seg_pad),
+                                       out_lowp=lowp)
 
         # ---- DynEdgeConv layers, last first
         for l in reversed(range(nconv)):
@@ -199,13 +224,13 @@ class _DynEdgeFunction(torch.autograd.Function):
             H1p = ops.round_up(H1, 32)
             g, PQ, mask = ctx.graphs[l], ctx.PQs[l], ctx.masks[l]
             g_out = dXcat[:, seg_off[l + 1]: seg_off[l + 1] + H2]
-            dPQ = torch.empty((N, 2 * H1p), dtype=torch.float32, device=dev)
+            dPQ = torch.empty((N, 2 * H1p), dtype=act, device=dev)
             dpre = torch.empty((max(g.rows, 1), H1p), dtype=dt, device=dev)
             dW2, db2 = ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, g_out, mask)   # also records h>0 bits
             ops.edgeconv_bwd(mode, g, PQ, H1p, H2, g_out, mask, ops.pack_weight(W2.t(), [H2], dt), dpre,
                              dPQ[:, :H1p])
             ops.edgeconv_dq_gather(mode, g, dpre, H1p, dPQ[:, H1p:])
-            dWpq, dbpq = ops.linear_wgrad(mode, dPQ, 2 * H1p, [(xin, _kw(Fin))], with_bias=True)
+            dWpq, dbpq = ops.linear_wgrad(mode, dPQ, 2 * H1p, _ksegs([(xin, Fin)]), with_bias=True)
             dWpq = dWpq[:, :Fin]
             dWp, dWq = dWpq[:H1], dWpq[H1p:H1p + H1]
             grads[4 * l] = torch.cat([dWp, dWq - dWp], dim=1)

@@ -215,18 +215,30 @@ def graph_globals(x: Tensor, ptr: Tensor, g: NeighbourTable, n_pulses: Tensor) -
     return out
 
 
-def concat_globals(x: Tensor, gv: Optional[Tensor], batch: Tensor, ld0: int) -> Tensor:
-    """``[x | gv[batch] | 0]`` with row pitch ``ld0`` (a multiple of 32)."""
+def concat_globals(x: Tensor, gv: Optional[Tensor], batch: Tensor, ld0: int,
+                   dtype: torch.dtype = torch.float32) -> Tensor:
+    """``[x | gv[batch] | 0]`` with row pitch ``ld0`` (a multiple of 32), as fp32 or bf16."""
     N, F = int(x.shape[0]), int(x.shape[1])
     G = 0 if gv is None else int(gv.shape[1])
-    x0 = torch.empty((N, ld0), dtype=torch.float32, device=x.device)
+    x0 = torch.empty((N, ld0), dtype=dtype, device=x.device)
     gvt = gv if gv is not None else x
-    _lib.check(_lib.lib().gn_concat_globals(_p(x), _rows(x, "x"), F, _p(gvt), G, _p(batch), N, _p(x0), ld0, _st()))
+    _lib.check(_lib.lib().gn_concat_globals(_p(x), _rows(x, "x"), F, _p(gvt), G, _p(batch), N, _p(x0), ld0,
+                                            int(dtype == torch.bfloat16), _st()))
     return x0
 
 
 # ------------------------------------------------------------------------------ dense layers
-Seg = Tuple[Tensor, int]   # (fp32 tensor [M, >=width] with unit column stride, real width)
+Seg = Tuple[Tensor, int]   # (fp32 or bf16 tensor [M, >=width] with unit column stride, kernel-side width)
+
+
+def act_dtype(mode: int) -> torch.dtype:
+    """Storage type of activations / activation gradients between kernels (``include/graphnet_amd.h``)."""
+    return mode_dtype(mode)
+
+
+def seg_unit(dtype: torch.dtype) -> int:
+    """Granularity of a segment's kernel-side width: one 16-byte load (4 floats / 8 bf16)."""
+    return 8 if dtype == torch.bfloat16 else 4
 
 
 def gemm_kunit(mode: int) -> int:
@@ -240,9 +252,12 @@ def _seg_arrays(segs: Sequence[Seg], with_kpad: bool, kunit: int = 32):
     lds = (ctypes.c_int64 * n)(*[_rows(s[0], "segment") for s in segs])
     widths = (ctypes.c_int32 * n)(*[int(s[1]) for s in segs])
     kpads = (ctypes.c_int32 * n)(*[round_up(int(s[1]), kunit) for s in segs]) if with_kpad else None
+    dt = segs[0][0].dtype
     for s in segs:
-        _need(s[0], torch.float32, "segment")
-    return n, ptrs, lds, widths, kpads
+        _need(s[0], dt, "segment")
+    if dt not in (torch.float32, torch.bfloat16):
+        raise TypeError("segments must be fp32 or bf16")
+    return n, ptrs, lds, widths, kpads, int(dt == torch.bfloat16)
 
 
 def pack_weight(W: Tensor, seg_widths: Sequence[int], dtype: torch.dtype, kunit: int = 32) -> Tensor:
@@ -264,7 +279,7 @@ def linear_fwd(mode: int, segs: Sequence[Seg], Wp: Tensor, n_real: int, bias: Op
                accum: bool = False, out_lowp: bool = False, out_cols: Optional[int] = None) -> Tensor:
     """``out[M, n_real] = epi(cat(segs) @ W^T + bias)`` on MFMA.  ``Wp`` from
     ``pack_weight(W, widths, dtype, kunit=gemm_kunit(mode))``."""
-    n, ptrs, lds, widths, kpads = _seg_arrays(segs, True, gemm_kunit(mode))
+    n, ptrs, lds, widths, kpads, a_lowp = _seg_arrays(segs, True, gemm_kunit(mode))
     M = int(segs[0][0].shape[0])
     Npad, Kp = int(Wp.shape[0]), int(Wp.shape[1])
     if out is None:
@@ -274,10 +289,11 @@ def linear_fwd(mode: int, segs: Sequence[Seg], Wp: Tensor, n_real: int, bias: Op
             out[:, n_real:].zero_()
     with _timed("linear_fwd"):
         _lib.check(_lib.lib().gn_linear_fwd(
-            mode, n, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(lds, ctypes.c_void_p),
+            mode, n, ctypes.cast(ptrs, ctypes.c_void_p), a_lowp, ctypes.cast(lds, ctypes.c_void_p),
             ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(kpads, ctypes.c_void_p), M, _p(Wp), Kp, Npad, n_real,
-            _p(bias), _p(gate), 0 if gate is None else _rows(gate, "gate"), int(relu), int(accum),
-            _p(out), _rows(out, "out"), int(out_lowp), _st()))
+            _p(bias), _p(gate), int(gate is not None and gate.dtype == torch.bfloat16),
+            0 if gate is None else _rows(gate, "gate"), int(relu), int(accum),
+            _p(out), _rows(out, "out"), int(out.dtype == torch.bfloat16), _st()))
     return out
 
 
@@ -285,8 +301,7 @@ def linear_wgrad(mode: int, dY: Tensor, n1: int, segs: Sequence[Seg], out: Optio
                  accum: bool = False, with_bias: bool = False):
     """``dW[n1, sum widths] (+)= dY[:, :n1]^T @ cat(segs)`` (deterministic split reduction).
     ``with_bias``: also return ``db[n1] = colsum(dY)`` from the same pass -> ``(dW, db)``."""
-    _need(dY, torch.float32, "dY")
-    n, ptrs, lds, widths, _ = _seg_arrays(segs, False)
+    n, ptrs, lds, widths, _, x_lowp = _seg_arrays(segs, False)
     M = int(dY.shape[0])
     ktot = sum(int(s[1]) for s in segs)
     L = _lib.lib()
@@ -300,7 +315,8 @@ def linear_wgrad(mode: int, dY: Tensor, n1: int, segs: Sequence[Seg], out: Optio
     if out is None:
         out = torch.empty((n1, ktot), dtype=torch.float32, device=dev)
     with _timed("linear_wgrad"):
-        _lib.check(L.gn_linear_wgrad(mode, _p(dY), _rows(dY, "dY"), n1, n, ctypes.cast(ptrs, ctypes.c_void_p),
+        _lib.check(L.gn_linear_wgrad(mode, _p(dY), int(dY.dtype == torch.bfloat16), _rows(dY, "dY"), n1, n,
+                                     ctypes.cast(ptrs, ctypes.c_void_p), x_lowp,
                                      ctypes.cast(lds, ctypes.c_void_p), ctypes.cast(widths, ctypes.c_void_p), M,
                                      _p(slab), _p(dbp), _p(out), _p(db), int(accum), _st()))
     return (out, db) if with_bias else out
@@ -320,23 +336,37 @@ def colsum(X: Tensor, C: int, out: Optional[Tensor] = None, accum: bool = False)
 
 # ------------------------------------------------------------------------------ EdgeConv
 def edgeconv_fwd(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, W2p: Tensor, b2: Tensor, H2: int,
-                 out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
-    """``out[i] = sum_j relu(relu(P[i]+Q[j]) W2^T + b2)``; returns (out fp32 [N,H2], relu bit mask)."""
+                 out: Optional[Tensor] = None, coord_cols: Optional[Sequence[int]] = None):
+    """``out[i] = sum_j relu(relu(P[i]+Q[j]) W2^T + b2)``; returns (out [N,H2] in the mode's activation
+    type, relu bit mask) or, with ``coord_cols`` (<= 8 output columns), (out, mask, coords fp32 [N, 8])
+    where ``coords[:, d]`` is the fp32 value of column ``coord_cols[d]`` (next layer's k-NN input)."""
     _need(PQ, mode_dtype(mode), "PQ"); _need(W2p, mode_dtype(mode), "W2p"); _need(b2, torch.float32, "b2")
     N = g.N
     if out is None:
-        out = torch.empty((N, H2), dtype=torch.float32, device=PQ.device)
+        out = torch.empty((N, H2), dtype=act_dtype(mode), device=PQ.device)
+    _need(out, act_dtype(mode), "out")
     nbytes = int(_lib.lib().gn_edgeconv_saved_bytes(N, g.K, H1p, H2))
     mask = torch.empty(nbytes, dtype=torch.uint8, device=PQ.device)     # opaque saved-for-backward buffer
+    coords, cc, nc = None, None, 0
+    if coord_cols is not None:
+        nc = len(coord_cols)
+        if nc > 8:
+            raise ValueError("at most 8 coordinate columns")
+        coords = torch.zeros((max(N, 1), 8), dtype=torch.float32, device=PQ.device)
+        cc = (ctypes.c_int32 * max(nc, 1))(*[int(c) for c in coord_cols])
     with _timed("edgeconv_fwd"):
         _lib.check(_lib.lib().gn_edgeconv_fwd(mode, *g.c_args(), _p(PQ), H1p, _p(W2p), _p(b2), H2, _p(out),
-                                              _rows(out, "out"), _p(mask), _st()))
+                                              _rows(out, "out"), _p(coords),
+                                              None if cc is None else ctypes.cast(cc, ctypes.c_void_p), nc,
+                                              _p(mask), _st()))
+    if coord_cols is not None:
+        return out, mask, coords[:N]
     return out, mask
 
 
 def edgeconv_bwd(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, H2: int, gout: Tensor, mask: Tensor,
                  W2Tp: Tensor, dpre: Tensor, dP: Tensor) -> None:
-    _need(gout, torch.float32, "gout"); _need(dP, torch.float32, "dP")
+    _need(gout, act_dtype(mode), "gout"); _need(dP, act_dtype(mode), "dP")
     with _timed("edgeconv_bwd"):
         _lib.check(_lib.lib().gn_edgeconv_bwd(mode, *g.c_args(), _p(PQ), H1p, H2, _p(gout), _rows(gout, "gout"),
                                               _p(mask), _p(W2Tp), int(W2Tp.shape[1]), _p(dpre), _p(dP),
@@ -347,6 +377,7 @@ def edgeconv_dw2(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, H1: int, H2
                  mask: Tensor) -> Tuple[Tensor, Tensor]:
     """Returns (dW2 [H2, H1], db2 [H2]).  Must run before :func:`edgeconv_bwd` of the same layer."""
     L = _lib.lib()
+    _need(gout, act_dtype(mode), "gout")
     nslab = int(L.gn_edgeconv_dw2_slabs(mode, g.N, g.K, H1p, H2))
     dev = PQ.device
     slab = torch.empty(nslab * H2 * H1, dtype=torch.float32, device=dev)
@@ -364,6 +395,7 @@ def edgeconv_dw2(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, H1: int, H2
 
 def edgeconv_dq_gather(mode: int, g: NeighbourTable, dpre: Tensor, H1p: int, dQ: Tensor) -> None:
     g.build_reverse()
+    _need(dQ, act_dtype(mode), "dQ")
     with _timed("edgeconv_dq_gather"):
         _lib.check(_lib.lib().gn_edgeconv_dq_gather(mode, _p(dpre), H1p, _p(g.rev_ptr), _p(g.rev_rows), g.N, _p(dQ),
                                                     _rows(dQ, "dQ"), _st()))
@@ -388,13 +420,20 @@ def segment_pool_fwd(x: Tensor, C: int, ptr: Tensor, schemes: Sequence[str], nee
 
 
 def segment_pool_bwd(gout: Tensor, C: int, ptr: Tensor, batch: Tensor, N: int, schemes: Sequence[str],
-                     amin: Tensor, amax: Tensor, gate: Optional[Tensor]) -> Tensor:
+                     amin: Tensor, amax: Tensor, gate: Optional[Tensor],
+                     dtype: torch.dtype = torch.float32) -> Tensor:
     gout = gout.contiguous()
     _need(gout, torch.float32, "gout")
-    dx = torch.empty((N, C), dtype=torch.float32, device=gout.device)
+    if gate is not None:
+        _need(gate, torch.float32, "gate")
+    ldx = round_up(C, 8)                               # 16-byte row pitch for either type; pad columns = 0
+    dx = torch.empty((N, ldx), dtype=dtype, device=gout.device)
+    if ldx != C:
+        dx[:, C:].zero_()
     c = _codes(schemes)
     with _timed("segment_pool_bwd"):
         _lib.check(_lib.lib().gn_segment_pool_bwd(_p(gout), C, _p(ptr), _p(batch), N, ctypes.cast(c, ctypes.c_void_p),
                                                   len(schemes), _p(amin), _p(amax), _p(gate),
-                                                  0 if gate is None else _rows(gate, "gate"), _p(dx), C, _st()))
-    return dx
+                                                  0 if gate is None else _rows(gate, "gate"), _p(dx), ldx,
+                                                  int(dtype == torch.bfloat16), _st()))
+    return dx if ldx == C else dx[:, :C]

@@ -13,6 +13,11 @@
  *   - return value: 0 on success, otherwise a hipError_t code; gn_last_error() has the text;
  *   - mode: 0 = f32 operands (v_mfma_f32_32x32x2_f32, parity mode), 1 = bf16 operands
  *     (v_mfma_f32_32x32x16_bf16); accumulation is fp32 in both; "T" below is float or bf16;
+ *   - activations and their gradients between the kernels ("act" tensors: x0, conv outputs, dPQ,
+ *     d_out, post-MLP hidden layers) are T: fp32 in mode 0, bf16 in mode 1 (a GEMM would round them
+ *     to bf16 on load anyway, so keeping them as bf16 in HBM halves the bytes without changing a
+ *     result); k-NN coordinates, the last post-MLP output (pooling input), pooled features,
+ *     weights, biases and every weight gradient stay fp32 in both modes;
  *   - layout: batched CSR — x[N, ld] row-major fp32, ptr[B+1] int32 event offsets,
  *     batch[N] int32 event ids, neighbour table nbr[N, K] int32 (-1 padded) + overflow list.
  */
@@ -73,30 +78,32 @@ int gn_ptr_to_batch(const int32_t* ptr, int32_t B, int32_t* batch, void* stream)
 int gn_graph_globals(const float* x, int64_t ldx, int32_t F, const int32_t* ptr, int32_t B,
                      const int32_t* nbr, const int32_t* ovf, int32_t K, const int32_t* n_pulses,
                      float* out, void* stream);
-/* "distribute" + cat (dynedge.py:308-319) as a gather: x0[i] = [x[i] | gv[batch[i]] | 0-pad to ld0] */
+/* "distribute" + cat (dynedge.py:308-319) as a gather: x0[i] = [x[i] | gv[batch[i]] | 0-pad to ld0];
+ * x0 is fp32, or bf16 when out_lowp */
 int gn_concat_globals(const float* x, int64_t ldx, int32_t F, const float* gv, int32_t G,
-                      const int32_t* batch, int32_t N, float* x0, int32_t ld0, void* stream);
+                      const int32_t* batch, int32_t N, void* x0, int32_t ld0, int32_t out_lowp, void* stream);
 
 /* ---- dense per-node layers (torch.nn.Linear at dynedge.py:198-231) -------------------- */
 
 /* C[M, Nreal] = epi(sum_s A_s[M, width_s] . Wp[:, seg s]^T + bias); Wp: T[Npad][Kp] packed so
- * that segment s occupies kpad_s (multiple of 32) columns; A_s fp32 with row pitch ld_s.
- * a_ptr/a_ld/a_width/a_kpad: HOST arrays of nseg entries.  gate: output *= (gate[m,n] > 0).
- * out_lowp: C is T instead of fp32 (bf16 mode only). */
-int gn_linear_fwd(int32_t mode, int32_t nseg, const float* const* a_ptr, const int64_t* a_ld,
+ * that segment s occupies kpad_s (multiple of 32) columns; A_s rows with pitch ld_s (elements), fp32 or
+ * (a_lowp, mode 1) bf16 — widths/pitches multiples of 4 resp. 8, pad columns up to the multiple hold 0.
+ * a_ptr/a_ld/a_width/a_kpad: HOST arrays of nseg entries.  gate: output *= (gate[m,n] > 0), fp32 or
+ * (gate_lowp) bf16.  out_lowp: C is bf16 instead of fp32 (mode 1).  accum: C += (in C's own type). */
+int gn_linear_fwd(int32_t mode, int32_t nseg, const void* const* a_ptr, int32_t a_lowp, const int64_t* a_ld,
                   const int32_t* a_width, const int32_t* a_kpad, int32_t M,
                   const void* Wp, int32_t Kp, int32_t Npad, int32_t Nreal,
-                  const float* bias, const float* gate, int64_t ldgate, int32_t relu, int32_t accum,
-                  void* C, int64_t ldc, int32_t out_lowp, void* stream);
+                  const float* bias, const void* gate, int32_t gate_lowp, int64_t ldgate, int32_t relu,
+                  int32_t accum, void* C, int64_t ldc, int32_t out_lowp, void* stream);
 
 /* dW[N1, sum width_s] (+)= dY[M,N1]^T . [X_0 | X_1 | ...] and, if db != NULL, db[N1] (+)= colsum(dY)
  * (the bias gradient, produced by the same pass in bf16 mode).  Scratch: slab >= parts*N1*Ktot floats,
  * db_part >= max(parts, gn_colsum_blocks(M))*N1 floats, parts = gn_linear_wgrad_parts().
- * x_width: HOST int[nseg]. */
+ * x_width: HOST int[nseg].  dY / X rows are fp32 or (dy_lowp / x_lowp, mode 1) bf16. */
 int32_t gn_linear_wgrad_parts(int32_t mode, int32_t M, int32_t N1, int32_t nseg, const int32_t* x_width_host);
-int gn_linear_wgrad(int32_t mode, const float* dY, int64_t lddy, int32_t N1, int32_t nseg,
-                    const float* const* x_ptr, const int64_t* x_ld, const int32_t* x_width, int32_t M,
-                    float* slab, float* db_part, float* dW, float* db, int32_t accum, void* stream);
+int gn_linear_wgrad(int32_t mode, const void* dY, int32_t dy_lowp, int64_t lddy, int32_t N1, int32_t nseg,
+                    const void* const* x_ptr, int32_t x_lowp, const int64_t* x_ld, const int32_t* x_width,
+                    int32_t M, float* slab, float* db_part, float* dW, float* db, int32_t accum, void* stream);
 
 /* out[C] (+)= column sums of X[M, C]; part: >= gn_colsum_blocks(M)*C floats */
 int32_t gn_colsum_blocks(int32_t M);
@@ -109,10 +116,14 @@ int gn_reduce_slabs(const float* slab, int32_t nslab, int64_t count, float* out,
  * backward needs (layout: graphnet_amd/csrc/common.hpp saved_layout()). */
 int64_t gn_edgeconv_saved_bytes(int32_t N, int32_t K, int32_t H1p, int32_t H2);
 
-/* out[i, :H2] = sum_slots relu(relu(P[i]+Q[j]) . W2^T + b2); PQ: T[N, 2*H1p]; W2p: T[ceil128(H2)][H1p] */
+/* out[i, :H2] = sum_slots relu(relu(P[i]+Q[j]) . W2^T + b2); PQ: T[N, 2*H1p]; W2p: T[ceil128(H2)][H1p];
+ * out: T[N, ldo].  coords (optional): fp32 [N][8], coords[i][d] = the fp32 value of output column
+ * coord_cols_host[d], d < ncoord <= 8 — the coordinates DynEdgeConv re-runs k-NN on (layers.py:63-67),
+ * kept in fp32 beside a bf16 `out`. */
 int gn_edgeconv_fwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
                     const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p,
-                    const void* W2p, const float* b2, int32_t H2, float* out, int64_t ldo,
+                    const void* W2p, const float* b2, int32_t H2, void* out, int64_t ldo,
+                    float* coords, const int32_t* coord_cols_host, int32_t ncoord,
                     void* saved, void* stream);
 /* dW2 / db2 partials: slab[nslab][H2][H1], db2_part[nslab][H2], nslab = gn_edgeconv_dw2_slabs();
  * reduce with gn_reduce_slabs.  Must run BEFORE gn_edgeconv_bwd of the same layer (it also
@@ -120,16 +131,16 @@ int gn_edgeconv_fwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre,
 int32_t gn_edgeconv_dw2_slabs(int32_t mode, int32_t N, int32_t K, int32_t H1p, int32_t H2);
 int gn_edgeconv_dw2(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
                     const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H1,
-                    int32_t H2, const float* gout, int64_t ldg, void* saved,
+                    int32_t H2, const void* gout, int64_t ldg, void* saved,
                     float* slab, float* db2_part, void* stream);
-/* dP[N,H1p] (fp32, pitch ldp) and dpre rows T[(N*S+N), H1p]; W2Tp: T[ceil128(H1p)][H2p] */
+/* gout: T[N, ldg]; dP: T[N, ldp] and dpre rows T[(N*S+N), H1p]; W2Tp: T[ceil128(H1p)][H2p] */
 int gn_edgeconv_bwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
                     const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H2,
-                    const float* gout, int64_t ldg, const void* saved, const void* W2Tp, int32_t H2p,
-                    void* dpre, float* dP, int64_t ldp, void* stream);
-/* dQ[j] = sum of dpre rows that gathered from j (ascending row id) */
+                    const void* gout, int64_t ldg, const void* saved, const void* W2Tp, int32_t H2p,
+                    void* dpre, void* dP, int64_t ldp, void* stream);
+/* dQ[j] (T[N, ldq]) = sum of dpre rows that gathered from j (ascending row id, fp32 accumulation) */
 int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int32_t* rev_ptr,
-                          const int32_t* rev_rows, int32_t N, float* dQ, int64_t ldq, void* stream);
+                          const int32_t* rev_rows, int32_t N, void* dQ, int64_t ldq, void* stream);
 
 /* ---- pooling (torch_scatter.scatter_{min,max,sum,mean}, dynedge.py:251-264) ------------ */
 /* codes: HOST int[ns], 0 = min, 1 = max, 2 = sum, 3 = mean; out[B, ns*C] */
@@ -138,7 +149,8 @@ int gn_segment_pool_fwd(const float* x, int64_t ldx, int32_t C, const int32_t* p
                         void* stream);
 int gn_segment_pool_bwd(const float* gout, int32_t C, const int32_t* ptr, const int32_t* batch, int32_t N,
                         const int32_t* codes_host, int32_t ns, const int32_t* argmin, const int32_t* argmax,
-                        const float* gate, int64_t ldgate, float* dx, int64_t lddx, void* stream);
+                        const float* gate, int64_t ldgate, void* dx, int64_t lddx, int32_t dx_lowp, void* stream);
+/* (dx: fp32, or bf16 when dx_lowp) */
 
 #ifdef __cplusplus
 }

@@ -182,6 +182,19 @@ def test_linear_fwd_segments_and_epilogues(name, mode, tol):
     if mode == 1:
         y = ops.linear_fwd(mode, segs, Wp, 336, bias=bias.to(DEV), out_lowp=True)
         assert y.dtype == torch.bfloat16 and rel_err(y.float(), ref) < tol
+        # bf16 activation rows (what the model passes in bf16 mode): 16-byte granularity = 8 columns;
+        # the result must equal the fp32-row call on the same (bf16-representable) values bit for bit
+        xs16 = [x.bfloat16() for x in xs]
+        segs16 = [(x.to(DEV), s[1]) for x, s in zip(xs16, segs)]
+        segs32 = [(x.float().to(DEV), s[1]) for x, s in zip(xs16, segs)]
+        gate16 = gate.bfloat16().to(DEV)
+        ya = ops.linear_fwd(mode, segs16, Wp, 336, bias=bias.to(DEV), gate=gate16)
+        yb = ops.linear_fwd(mode, segs32, Wp, 336, bias=bias.to(DEV), gate=gate16.float())
+        assert torch.equal(ya, yb), "bf16 rows / bf16 gate must not change the arithmetic"
+        out16 = base.bfloat16().to(DEV)
+        ops.linear_fwd(mode, segs16, Wp, 336, bias=bias.to(DEV), out=out16[:, 32:368], accum=True)
+        assert out16.dtype == torch.bfloat16 and rel_err(out16.float(), exp) < tol, "accumulate into a bf16 view"
+        assert torch.equal(out16[:, :32].float().cpu(), base.bfloat16()[:, :32].float()), "outside the view untouched"
 
 
 @pytest.mark.parametrize("name,mode,tol", MODES)
@@ -204,6 +217,15 @@ def test_linear_wgrad_and_colsum(name, mode, tol):
     assert rel_err(dW3, dY3.t() @ x3) < tol and rel_err(db3, dY3.sum(0)) < (1e-5 if mode == 0 else 1e-2)
     cs = ops.colsum(dY.to(DEV), 336)
     assert rel_err(cs, dY.sum(0)) < 1e-5
+    if mode == 1:
+        # bf16 dY / X rows: identical arithmetic to fp32 rows holding the same bf16-representable values
+        dY16, xa16, xb16 = dY.bfloat16(), xa.bfloat16(), xb.bfloat16()
+        a = ops.linear_wgrad(mode, dY16.to(DEV), 336, [(xa16.to(DEV), 32), (xb16.to(DEV), 256)], with_bias=True)
+        b_ = ops.linear_wgrad(mode, dY16.float().to(DEV), 336, [(xa16.float().to(DEV), 32), (xb16.float().to(DEV), 256)],
+                              with_bias=True)
+        assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1])
+        c = ops.linear_wgrad(mode, dY16.to(DEV), 336, [(xa16.float().to(DEV), 32), (xb16.float().to(DEV), 256)])
+        assert torch.equal(c, a[0]), "mixed bf16 dY / fp32 X rows"
 
 
 # ------------------------------------------------------------------------------ EdgeConv
@@ -237,8 +259,20 @@ def test_edgeconv_forward(oracle, name, mode, tol, k, F, H1, H2):
     Wpq[H1p:H1p + H1] = W1[:, F:]
     bpq = torch.zeros(2 * H1p, device=DEV); bpq[:H1] = b1
     PQ = ops.linear_fwd(mode, [(x.to(DEV), F)], ops.pack_weight(Wpq, [F], dt, ops.gemm_kunit(mode)), 2 * H1p, bias=bpq, out_lowp=(mode == 1))
-    out, _mask = ops.edgeconv_fwd(mode, t, PQ, H1p, ops.pack_weight(W2, [H1], dt), b2, H2)
+    out, _mask, coords = ops.edgeconv_fwd(mode, t, PQ, H1p, ops.pack_weight(W2, [H1], dt), b2, H2,
+                                          coord_cols=[0, 1, 2, 5])
+    assert out.dtype == ops.act_dtype(mode)
     assert rel_err(out, ref) < tol, name
+    # fp32 copy of the k-NN coordinate columns: the unrounded values of the same result
+    assert coords.dtype == torch.float32 and rel_err(coords[:, :4], ref[:, [0, 1, 2, 5]]) < tol
+    if mode == 0:
+        assert torch.equal(coords[:, :4], out[:, [0, 1, 2, 5]])
+    else:
+        # bf16 out = RNE of the fp32 value; centres with an overflow (k+1-th) neighbour add that row to the
+        # already rounded sum (second rounding), so they are only equal to one bf16 ulp
+        plain = (t.ovf < 0)
+        assert torch.equal(coords[plain][:, :4].bfloat16(), out[plain][:, [0, 1, 2, 5]])
+        assert rel_err(coords[:, :4], out[:, [0, 1, 2, 5]].float()) < 1e-2
 
 
 @pytest.mark.parametrize("name,mode,tol", MODES)
@@ -297,8 +331,8 @@ def test_segment_pool_forward_backward(oracle):
 
 def test_persistent_kernels_match_generic_kernels(oracle):
     """A/B: the persistent operand-stationary bf16 kernels (edgeconv_v2.hip) against the generic
-    tiled kernels (GN_DISABLE_V2=1) on identical bf16 inputs: fp32 results agree to 1e-4 of the
-    tensor's max (accumulation order), bf16 dpre rows to one bf16 ulp."""
+    tiled kernels (GN_DISABLE_V2=1) on identical bf16 inputs: fp32 results (weight gradients) agree
+    to 1e-4 of the tensor's max (accumulation order), bf16 tensors (out, dP|dQ, dpre) to one bf16 ulp."""
     import os
     from graphnet_amd import ops
     mode, dt = 1, torch.bfloat16
@@ -316,20 +350,22 @@ def test_persistent_kernels_match_generic_kernels(oracle):
         PQ = ops.linear_fwd(mode, [(x.to(DEV), F)], ops.pack_weight(Wpq, [F], dt, ops.gemm_kunit(mode)), 2 * H1p, bias=bpq, out_lowp=True)
         W2p, W2Tp = ops.pack_weight(W2, [H1], dt), ops.pack_weight(W2.t().contiguous(), [H2], dt)
         torch.manual_seed(5)
-        gout = torch.randn(N, H2, device=DEV)
+        gout = torch.randn(N, H2, device=DEV).to(dt)            # activations / gradients are bf16 in bf16 mode
         res = {}
         for tag, flag in (("v2", "0"), ("v1", "1")):
             os.environ["GN_DISABLE_V2"] = flag
             out, saved = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2)
             dW2, db2 = ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, gout, saved)
-            dPQ = torch.zeros(N, 2 * H1p, device=DEV)
+            dPQ = torch.zeros(N, 2 * H1p, dtype=dt, device=DEV)
             dpre = torch.zeros(g.rows, H1p, dtype=dt, device=DEV)
             ops.edgeconv_bwd(mode, g, PQ, H1p, H2, gout, saved, W2Tp, dpre, dPQ[:, :H1p])
             ops.edgeconv_dq_gather(mode, g, dpre, H1p, dPQ[:, H1p:])
             torch.cuda.synchronize()
             res[tag] = dict(out=out, dW2=dW2, db2=db2, dPQ=dPQ, dpre=dpre.float())
         os.environ["GN_DISABLE_V2"] = "0"
-        for k in ("out", "dW2", "db2", "dPQ"):
+        for k in ("dW2", "db2"):
             assert rel_err(res["v2"][k], res["v1"][k]) < 1e-4, (F, H1, k)
+        for k in ("out", "dPQ"):                                 # bf16 tensors: equal up to one bf16 ulp
+            assert rel_err(res["v2"][k], res["v1"][k]) < 1e-2, (F, H1, k)
         nrows = N * 8 + int(g.ovf_cnt.item())
         assert rel_err(res["v2"]["dpre"][:nrows], res["v1"]["dpre"][:nrows]) < 1e-2, (F, H1, "dpre")

@@ -22,7 +22,7 @@ g = ops.knn_graph(b.x, [0, 1, 2], batch32, ptr32, 8)
 torch.manual_seed(0)
 F, H1, H2 = 256, 336, 256
 H1p = ops.round_up(H1, 32)
-x = torch.randn(N, F, device=dev)
+x = torch.randn(N, F, device=dev).to(dt)
 W1 = torch.randn(H1, 2 * F, device=dev) * 0.05
 W2 = torch.randn(H2, H1, device=dev) * 0.05
 b2 = torch.randn(H2, device=dev) * 0.1
@@ -32,10 +32,10 @@ Wpq[H1p:H1p + H1] = W1[:, F:]
 PQ = ops.linear_fwd(mode, [(x, F)], ops.pack_weight(Wpq, [F], dt, ops.gemm_kunit(mode)), 2 * H1p, out_lowp=True)
 W2p = ops.pack_weight(W2, [H1], dt)
 W2Tp = ops.pack_weight(W2.t().contiguous(), [H2], dt)
-gout = torch.randn(N, H2, device=dev)
+gout = torch.randn(N, H2, device=dev).to(dt)
 out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2)
 ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, gout, mask)
-dPQ = torch.empty(N, 2 * H1p, device=dev)
+dPQ = torch.empty(N, 2 * H1p, dtype=dt, device=dev)
 dpre = torch.empty(g.rows, H1p, dtype=dt, device=dev)
 torch.cuda.synchronize()
 ops.enable_timers(True)

@@ -9,11 +9,11 @@ dev, mode, dt = "cuda", 1, torch.bfloat16
 M = 158439
 ku = ops.gemm_kunit(mode)
 torch.manual_seed(0)
-x = torch.randn(M, 256, device=dev)
-xs = [torch.randn(M, 32, device=dev)] + [torch.randn(M, 256, device=dev) for _ in range(4)]
+x = torch.randn(M, 256, device=dev).to(dt)
+xs = [torch.randn(M, 32, device=dev).to(dt)] + [torch.randn(M, 256, device=dev).to(dt) for _ in range(4)]
 Wpq = ops.pack_weight(torch.randn(704, 256, device=dev), [256], dt, ku)
 Wpost = ops.pack_weight(torch.randn(336, 32 + 1024, device=dev), [32, 256, 256, 256, 256], dt, ku)
-dY = torch.randn(M, 704, device=dev)
+dY = torch.randn(M, 704, device=dev).to(dt)
 torch.cuda.synchronize()
 def t(fn, n=iters):
     fn(); torch.cuda.synchronize()
@@ -33,6 +33,11 @@ if which in ("post", "all"):
 if which in ("wgrad", "all"):
     us = t(lambda: ops.linear_wgrad(mode, dY, 704, [(x, 256)]))
     print(f"wgrad     [704x{M}]x[{M}x256]:            {us:8.1f} us  {2*M*256*704/us/1e6:7.1f} TF/s")
+if which in ("dx", "all"):
+    Wdx = ops.pack_weight(torch.randn(256, 704, device=dev), [704], dt, ku)
+    acc = torch.zeros(M, 256, dtype=dt, device=dev)
+    us = t(lambda: ops.linear_fwd(mode, [(dY, 704)], Wdx, 256, out=acc, accum=True))
+    print(f"dx   gemm [{M}x704]x[256] accum:          {us:8.1f} us  {2*M*704*256/us/1e6:7.1f} TF/s")
 if which in ("colsum", "all"):
-    us = t(lambda: ops.colsum(dY, 336))
+    us = t(lambda: ops.colsum(dY.float(), 336))
     print(f"colsum    [{M}x336 of 704]:               {us:8.1f} us  {M*336*4/us/1e6:7.2f} TB/s")
