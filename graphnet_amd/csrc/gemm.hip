@@ -504,6 +504,9 @@ static hipError_t launch_gemm_nt_t(const Segs& a, int M, const void* Wp, int Kp,
     return launch_gemm_nt_cfg<T, 128, 32, OutT, AT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
 }
 
+hipError_t launch_gemm_nt_v2(const Segs& a, int M, const void* Wp, int Kp, int Npad, int N, const Epi& epi, void* C,
+                             long long ldc, int out_lowp, hipStream_t st);
+
 // mode: 0 = f32 MFMA, 1 = bf16 MFMA.  a_lowp: the A segments are bf16 rows (mode 1 only).
 // out_lowp: C is bf16 (mode 1 only).
 hipError_t launch_gemm_nt(int mode, const Segs& a, int a_lowp, int M, const void* Wp, int Kp, int Npad, int Nreal,
@@ -520,6 +523,9 @@ hipError_t launch_gemm_nt(int mode, const Segs& a, int a_lowp, int M, const void
         return launch_gemm_nt_t<float, float, float>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
     }
     if (a_lowp) {
+        // short single-segment contractions: persistent weights-stationary kernel (gemm_v2.hip)
+        const hipError_t e2 = launch_gemm_nt_v2(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, out_lowp, st);
+        if (e2 != hipErrorNotSupported) return e2;
         if (out_lowp) return launch_gemm_nt_t<__bf16, __bf16, __bf16>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
         return launch_gemm_nt_t<__bf16, float, __bf16>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
     }

@@ -1,0 +1,274 @@
+// graphnet_amd/csrc/gemm_v2.hip — weights-stationary per-node GEMM for short contractions (bf16).
+//
+//   C[M, N] = epi( A[M, K] . W[N, K]^T + bias )        K <= 352, M = all pulses of the batch
+//
+// The per-node layers of DynEdge with a short K (P|Q projection K = F_in, post-MLP layer 2, the
+// input gradients of the post MLP; torch.nn.Linear at models/gnn/dynedge.py:198-231) are streaming
+// problems: A is read once, C written once, W (<= 0.5 MB) is tiny.  Tiled GEMMs re-stage W for every
+// output tile and scatter 2-byte stores; here instead
+//   * a persistent workgroup owns ONE column population (NW waves x 32 columns) and keeps its W slice
+//     in VGPRs for the whole launch (KSTEPS x 16 bytes per lane);
+//   * it walks a contiguous range of 64-row tiles of A: global -> registers (prefetch one tile ahead)
+//     -> LDS (double buffered), every wave multiplies the same A tile with its own W slice;
+//   * MFMA operands are swapped (W is the "A" operand) so that a lane holds 4 CONSECUTIVE output
+//     columns of one row: bias/relu, one packed convert, one 8/16-byte LDS write into a staging tile;
+//   * the staging tile leaves as full 16-byte row chunks (coalesced), where the optional relu gate
+//     (output *= gate > 0, bf16 rows) is applied.
+//   * populations that share a row range are placed on the same XCD (blockIdx -> XCD is round-robin),
+//     so A comes from HBM once and from that XCD's L2 for the other populations.
+// Loads that are prefetched are always consumed BEFORE the tile's global stores are issued (vmcnt
+// retires in order: a load consumed after a store waits for the store's write acknowledgement).
+// HBM-bound: algorithmic bytes = M*(K*2 + N*sizeof(OutT)).
+#include "common.hpp"
+#include <cstdlib>
+
+namespace gn {
+
+typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+typedef float f32x2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pk2(float lo, float hi) {
+    const f32x2_v v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_v));   // v_cvt_pk_bf16_f32
+}
+
+// LDS pitch (bytes, rows are multiples of 16 bytes) with (pitch/4) % 8 == 4: the 16-byte accesses of 8
+// consecutive rows then start at 8 distinct multiples of 4 banks, i.e. cover all 32 banks once
+__host__ __device__ constexpr int pitch4(int row_bytes) {
+    return row_bytes + (((row_bytes / 4) % 8 == 4) ? 0 : 16);
+}
+
+constexpr int G2_ROWS = 64;
+
+template <int KSTEPS, int NW, typename OutT, bool GATE>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_v2_kernel(
+    const __bf16* __restrict__ A, long long lda, int M, int Kw,          // A rows: Kw real columns (% 8 == 0)
+    const __bf16* __restrict__ Wp, int Kp, int Npad, int N,               // Wp: [Npad][Kp] packed weights
+    const float* __restrict__ bias, const __bf16* __restrict__ gate, long long ldgate, int relu,
+    OutT* __restrict__ C, long long ldc, int ntiles, int nranges, int P)
+{
+    constexpr int NT = NW * 64;
+    constexpr int KB = KSTEPS * 32;                      // bytes of one A row in LDS
+    constexpr int AP = pitch4(KB);
+    constexpr int CW = NW * 32;                          // columns of one population
+    constexpr int SP = pitch4(CW * (int)sizeof(OutT));
+    constexpr int ACH = KSTEPS * 2;                      // 16-byte chunks per A row
+    constexpr int ACPT = (G2_ROWS * ACH + NT - 1) / NT;  // ... per thread
+    constexpr int OEL = 16 / (int)sizeof(OutT);          // output elements per 16-byte chunk
+    constexpr int OCH = CW / OEL;                        // chunks per staged row
+    constexpr int OCPT = (G2_ROWS * OCH + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][G2_ROWS * AP];
+    __shared__ __attribute__((aligned(16))) unsigned char Stage[G2_ROWS * SP];
+    __shared__ __attribute__((aligned(16))) float Bias[CW];
+    static_assert(sizeof(As) + sizeof(Stage) + sizeof(Bias) <= 160 * 1024, "LDS budget");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // workgroup -> (population, row range); populations of one range share an XCD
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int pop = slot % P, range = (slot / P) * 8 + xcd;
+    if (range >= nranges) return;
+    const int per = (ntiles + nranges - 1) / nranges;
+    int tile = range * per;
+    const int tile_end = min(ntiles, tile + per);
+    if (tile >= tile_end) return;
+    const int col0 = pop * CW;                           // first output column of this workgroup
+
+    // stationary W slice: row n = col0 + 32*wave + r, k = 16*s + 8*h .. +8
+    bf16x8 w2[KSTEPS];
+    {
+        const int n = col0 + wave * 32 + r;
+        const bool nok = n < Npad;
+        const __bf16* wrow = Wp + (long long)(nok ? n : 0) * Kp + h * 8;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(wrow + s * 16);
+            if (!nok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.0f;
+            }
+            w2[s] = v;
+        }
+    }
+    // bias of this population's columns, in LDS (kept out of the VGPR budget)
+    for (int c = tid; c < CW; c += NT) Bias[c] = (bias && col0 + c < N) ? bias[col0 + c] : 0.0f;
+    const float lo = relu ? 0.0f : -3.0e38f;
+
+    u32x4 areg[ACPT];
+#define GN_G2_LOAD(t_)                                                                                \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < ACPT; ++i) {                                            \
+            const int id__ = tid + NT * i;                                                            \
+            const int row__ = id__ / ACH, c__ = id__ % ACH;                                           \
+            const long long m__ = (long long)(t_) * G2_ROWS + row__;                                  \
+            a_ok[i] = (t_) < tile_end && id__ < G2_ROWS * ACH && m__ < M && c__ * 8 < Kw;             \
+            const long long off__ = a_ok[i] ? m__ * lda + c__ * 8 : 0;                                \
+            areg[i] = *reinterpret_cast<const u32x4*>(A + off__);                                     \
+        }                                                                                             \
+    }
+#define GN_G2_WRITE(buf_)                                                                             \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < ACPT; ++i) {                                            \
+            const int id__ = tid + NT * i;                                                            \
+            const int row__ = id__ / ACH, c__ = id__ % ACH;                                           \
+            if (id__ < G2_ROWS * ACH)                                                                 \
+                *reinterpret_cast<u32x4*>(&As[buf_][row__ * AP + c__ * 16]) =                         \
+                    a_ok[i] ? areg[i] : (u32x4){0u, 0u, 0u, 0u};                                      \
+        }                                                                                             \
+    }
+    bool a_ok[ACPT];
+
+    GN_G2_LOAD(tile);
+    GN_G2_WRITE(0);
+    __syncthreads();
+
+    int buf = 0;
+    for (; tile < tile_end; ++tile, buf ^= 1) {
+        GN_G2_LOAD(tile + 1);
+
+        f32x16 acc0, acc1;                               // [n][m]: rows 0-31 / 32-63 of the tile
+        zero_acc(acc0); zero_acc(acc1);
+        {
+            const unsigned char* p0 = &As[buf][r * AP + h * 16];
+            const unsigned char* p1 = p0 + 32 * AP;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(p0 + s * 32);
+                const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(p1 + s * 32);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[s], x0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[s], x1, acc1, 0, 0, 0);
+            }
+        }
+        // epilogue: lane = tile row (r / 32 + r), registers 4g..4g+3 = columns 8g + 4h + (0..3) of the wave's block
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const f32x16& acc = rb ? acc1 : acc0;
+            unsigned char* srow = &Stage[(rb * 32 + r) * SP + (wave * 32 + 4 * h) * sizeof(OutT)];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(&Bias[wave * 32 + 8 * g + 4 * h]);
+                const float v0 = fmaxf(acc[4 * g + 0] + bv[0], lo), v1 = fmaxf(acc[4 * g + 1] + bv[1], lo);
+                const float v2 = fmaxf(acc[4 * g + 2] + bv[2], lo), v3 = fmaxf(acc[4 * g + 3] + bv[3], lo);
+                if constexpr (sizeof(OutT) == 2) {
+                    typedef unsigned int u32x2_v __attribute__((ext_vector_type(2)));
+                    const u32x2_v pk = {pk2(v0, v1), pk2(v2, v3)};
+                    *reinterpret_cast<u32x2_v*>(srow + 8 * g * sizeof(OutT)) = pk;
+                } else {
+                    *reinterpret_cast<f32x4*>(srow + 8 * g * sizeof(OutT)) = (f32x4){v0, v1, v2, v3};
+                }
+            }
+        }
+        GN_G2_WRITE(buf ^ 1);                            // consumes the prefetched A tile
+        __syncthreads();                                  // staging tile + next A tile complete
+
+        // optional gate rows of this tile: all loads first, so that none is consumed after a store
+        u32x4 greg[GATE ? OCPT : 1];
+        if constexpr (GATE) {
+#pragma unroll
+            for (int i = 0; i < OCPT; ++i) {
+                const int id = tid + NT * i;
+                const int row = id / OCH, c = id % OCH;
+                const long long m = (long long)tile * G2_ROWS + row;
+                const int col = col0 + c * OEL;
+                const bool ok = id < G2_ROWS * OCH && m < M && col < N;
+                greg[i] = *reinterpret_cast<const u32x4*>(gate + (ok ? m * ldgate + col : 0));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < OCPT; ++i) {
+            const int id = tid + NT * i;
+            const int row = id / OCH, c = id % OCH;
+            const long long m = (long long)tile * G2_ROWS + row;
+            const int col = col0 + c * OEL;
+            if (id < G2_ROWS * OCH && m < M && col < N) {
+                u32x4 v = *reinterpret_cast<const u32x4*>(&Stage[row * SP + c * 16]);
+                if constexpr (GATE && sizeof(OutT) == 2) {
+                    // bf16 gate > 0  <=>  its 16 bits, as a signed integer, > 0 (+0 / -0 / negatives excluded)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned int gw = greg[i][w];      // copy the element first (never bit_cast a vector element)
+                        const unsigned int mlo = ((int)(gw << 16) > 0) ? 0x0000ffffu : 0u;
+                        const unsigned int mhi = ((int)(gw & 0xffff0000u) > 0) ? 0xffff0000u : 0u;
+                        v[w] &= (mlo | mhi);
+                    }
+                }
+                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(C + m * ldc + col)) = v;
+            }
+        }
+        __syncthreads();                                  // Stage may be overwritten by the next tile
+    }
+#undef GN_G2_LOAD
+#undef GN_G2_WRITE
+}
+
+static bool g2_enabled() {
+    const char* e = getenv("GN_DISABLE_V2");
+    return !(e && e[0] == '1');
+}
+int device_cus();
+
+template <int KSTEPS, int NW, typename OutT>
+static hipError_t g2_launch(const void* A, long long lda, int M, int Kw, const void* Wp, int Kp, int Npad, int N,
+                            const float* bias, const void* gate, long long ldgate, int relu, void* C, long long ldc,
+                            hipStream_t st) {
+    constexpr int CW = NW * 32;
+    const int P = (N + CW - 1) / CW;
+    const int ntiles = (M + G2_ROWS - 1) / G2_ROWS;
+    int slots = device_cus() / 8;                        // workgroups per XCD (one per CU)
+    if (slots < P) slots = P;
+    const int rpx = slots / P;                           // row ranges per XCD
+    const int nranges = 8 * rpx;
+    if (gate) {
+        if constexpr (sizeof(OutT) == 2)
+            hipLaunchKernelGGL((gemm_nt_v2_kernel<KSTEPS, NW, OutT, true>), dim3(8 * rpx * P), dim3(NW * 64), 0, st,
+                               (const __bf16*)A, lda, M, Kw, (const __bf16*)Wp, Kp, Npad, N, bias, (const __bf16*)gate,
+                               ldgate, relu, (OutT*)C, ldc, ntiles, nranges, P);
+        else
+            return hipErrorNotSupported;
+    } else {
+        hipLaunchKernelGGL((gemm_nt_v2_kernel<KSTEPS, NW, OutT, false>), dim3(8 * rpx * P), dim3(NW * 64), 0, st,
+                           (const __bf16*)A, lda, M, Kw, (const __bf16*)Wp, Kp, Npad, N, bias, (const __bf16*)gate,
+                           ldgate, relu, (OutT*)C, ldc, ntiles, nranges, P);
+    }
+    return hipGetLastError();
+}
+
+// hipErrorNotSupported = outside the envelope (the caller uses the tiled kernel)
+hipError_t launch_gemm_nt_v2(const Segs& a, int M, const void* Wp, int Kp, int Npad, int N, const Epi& epi, void* C,
+                             long long ldc, int out_lowp, hipStream_t st) {
+    if (!g2_enabled() || a.nseg != 1 || epi.accum || M == 0) return hipErrorNotSupported;
+    if (epi.gate && (!epi.gate_lowp || !out_lowp || (epi.ldgate & 7))) return hipErrorNotSupported;
+    const int Kw = a.width[0];
+    const int oel = out_lowp ? 8 : 4;
+    if ((Kw & 7) || (a.ld[0] & 7) || (N % oel) || (ldc % oel) || (reinterpret_cast<uintptr_t>(C) & 15) ||
+        (epi.gate && (reinterpret_cast<uintptr_t>(epi.gate) & 15)) || (epi.bias && (reinterpret_cast<uintptr_t>(epi.bias) & 15)))
+        return hipErrorNotSupported;
+    const int ks = (Kw + 15) / 16;
+    if (ks * 16 > Kp) return hipErrorNotSupported;
+    const bool wide = !(N <= 256 || N % 256 == 0);       // 11 waves x 32 columns = 352 per population
+    const void* A = a.p[0];
+    const long long lda = a.ld[0];
+#define GN_G2_CASE(KS, NWV, OT)                                                                       \
+    {                                                                                                 \
+        if ((KS) * 16 > Kp) return hipErrorNotSupported;      /* the W slice reads KS k-steps */      \
+        return g2_launch<KS, NWV, OT>(A, lda, M, Kw, Wp, Kp, Npad, N, epi.bias, epi.gate, epi.ldgate, \
+                                      epi.relu, C, ldc, st);                                          \
+    }
+    if (out_lowp) {
+        if (!wide) {
+            if (ks <= 4) GN_G2_CASE(4, 8, __bf16);
+            if (ks <= 16) GN_G2_CASE(16, 8, __bf16);
+            if (ks <= 22) GN_G2_CASE(22, 8, __bf16);
+        } else {
+            if (ks <= 4) GN_G2_CASE(4, 11, __bf16);
+            if (ks <= 16) GN_G2_CASE(16, 11, __bf16);
+        }
+    } else if (!wide && !epi.gate) {
+        if (ks <= 16) GN_G2_CASE(16, 8, float);
+        if (ks <= 22) GN_G2_CASE(22, 8, float);
+    }
+#undef GN_G2_CASE
+    return hipErrorNotSupported;
+}
+
+}  // namespace gn

@@ -208,13 +208,15 @@ class _DynEdgeFunction(torch.autograd.Function):
                 dZ = ops.linear_fwd(mode, _ksegs([(dZ, Pt)]), ops.pack_weight(W.t(), [Pt], dt, ku), Pprev, gate=yprev,
                                     out_lowp=lowp, out_cols=ops.round_up(Pprev, 8))
             else:
+                # gradient w.r.t. the skip-cat input, segment 0 (the raw pulse features) excluded: nobody reads it
                 WT = torch.zeros((sum(seg_pad), Pt), dtype=torch.float32, device=dev)
                 off = 0
                 for s, (_, w) in enumerate(xs):
                     WT[seg_off[s]: seg_off[s] + w] = W[:, off: off + w].t()
                     off += w
-                dXcat = ops.linear_fwd(mode, _ksegs([(dZ, Pt)]), ops.pack_weight(WT, [Pt], dt, ku), sum(seg_pad),
-                                       out_lowp=lowp)
+                dXcat = torch.empty((N, sum(seg_pad)), dtype=act, device=dev)
+                ops.linear_fwd(mode, _ksegs([(dZ, Pt)]), ops.pack_weight(WT[seg_off[1]:], [Pt], dt, ku),
+                               sum(seg_pad) - seg_off[1], out=dXcat[:, seg_off[1]:])
 
         # ---- DynEdgeConv layers, last first
         for l in reversed(range(nconv)):

@@ -228,6 +228,48 @@ def test_linear_wgrad_and_colsum(name, mode, tol):
         assert torch.equal(c, a[0]), "mixed bf16 dY / fp32 X rows"
 
 
+def test_weights_stationary_gemm_matches_tiled():
+    """A/B: gemm_v2.hip (persistent, W in registers) against the tiled kernel (GN_DISABLE_V2=1) on the
+    shapes the model uses: same MFMA sequence per output -> fp32 outputs equal, bf16 outputs equal."""
+    import os
+    from graphnet_amd import ops
+    mode, dt = 1, torch.bfloat16
+    torch.manual_seed(4)
+    M = 5003                                           # ragged last tile
+    cases = [  # (K real, K pitch, N, bias, relu, gate, out bf16)
+        (256, 256, 704, True, False, False, True),     # P|Q projection
+        (24, 32, 256, True, False, False, True),       # layer-1 projection (17 features + pad)
+        (336, 336, 256, True, True, False, False),     # post-MLP layer 2 -> fp32 (pooling input)
+        (256, 256, 336, False, False, True, True),     # d(post layer 1 output), relu gate
+        (336, 336, 1024, False, False, False, True),   # d(skip-cat input)
+        (256, 256, 100, True, True, False, False),     # ragged N, fp32
+    ]
+    for (K, ldk, N, has_b, relu, has_g, lowp) in cases:
+        a = torch.randn(M, ldk).bfloat16()
+        a[:, K:] = 0
+        W = torch.randn(N, K) * 0.1
+        bias = torch.randn(N).to(DEV) if has_b else None
+        gate = torch.randn(M, ops.round_up(N, 8)).bfloat16().to(DEV) if has_g else None
+        Wp = ops.pack_weight(W.to(DEV), [K], dt, ops.gemm_kunit(mode))
+        res = {}
+        for tag, flag in (("v2", "0"), ("v1", "1")):
+            os.environ["GN_DISABLE_V2"] = flag
+            res[tag] = ops.linear_fwd(mode, [(a.to(DEV), K)], Wp, N, bias=bias, relu=relu, gate=gate, out_lowp=lowp,
+                                      out_cols=ops.round_up(N, 8))
+            torch.cuda.synchronize()
+        os.environ["GN_DISABLE_V2"] = "0"
+        ref = a[:, :K].float() @ W.bfloat16().float().t()
+        if has_b:
+            ref = ref + bias.cpu()
+        if relu:
+            ref = ref.relu()
+        if has_g:
+            ref = ref * (gate.cpu()[:, :N].float() > 0)
+        assert rel_err(res["v1"][:, :N], ref) < 2e-2, (K, N, "tiled vs torch")
+        assert torch.equal(res["v2"][:, :N], res["v1"][:, :N]), (K, N, "stationary vs tiled")
+        assert res["v2"].dtype == (dt if lowp else torch.float32)
+
+
 # ------------------------------------------------------------------------------ EdgeConv
 def _edgeconv_case(oracle, k=8, F=32, H1=336, H2=256, n_events=14, seed=6, dup=True):
     b = _batch(n_events, seed=seed)
