@@ -86,6 +86,57 @@ __global__ __launch_bounds__(256) void segment_pool_bwd_kernel(
     dx[(long long)i * lddx + c] = from_f32<OutT>(v);
 }
 
+// Same, 8 consecutive columns per thread (C % 8 == 0): 16/32-byte loads and stores instead of scalars.
+template <typename OutT>
+__global__ __launch_bounds__(256) void segment_pool_bwd8_kernel(
+    const float* __restrict__ gout /*[B, n*C]*/, int C, const int* __restrict__ ptr, const int* __restrict__ batch,
+    int N, PoolSchemes sch, const int* __restrict__ argmin, const int* __restrict__ argmax,
+    const float* __restrict__ gate, long long ldgate, OutT* __restrict__ dx, long long lddx)
+{
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    const int C8 = C >> 3;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(t / C8), c = (int)(t % C8) * 8;
+    if (i >= N) return;
+    const int g = batch[i];
+    const float n = (float)max(ptr[g + 1] - ptr[g], 1);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s < sch.n) {
+            const float* gp = gout + ((long long)g * sch.n + s) * C + c;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(gp), b = *reinterpret_cast<const f32x4*>(gp + 4);
+            const float go[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            const int code = sch.code[s];
+            if (code == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += go[e];
+            } else if (code == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += go[e] / n;
+            } else {
+                const int* ap = (code == 0 ? argmin : argmax) + (long long)g * C + c;
+                const i32x4_t p = *reinterpret_cast<const i32x4_t*>(ap), q = *reinterpret_cast<const i32x4_t*>(ap + 4);
+                const int ai[8] = {p[0], p[1], p[2], p[3], q[0], q[1], q[2], q[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (ai[e] == i) v[e] += go[e];
+            }
+        }
+    }
+    if (gate) {
+        const float* gp = gate + (long long)i * ldgate + c;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(gp), b = *reinterpret_cast<const f32x4*>(gp + 4);
+        const float gt[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (!(gt[e] > 0.0f)) v[e] = 0.0f;
+    }
+    OutT* dst = dx + (long long)i * lddx + c;
+    store4<OutT>(dst, v[0], v[1], v[2], v[3]);
+    store4<OutT>(dst + 4, v[4], v[5], v[6], v[7]);
+}
+
 hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr, int B, const int* codes, int ns,
                            float* out, int* argmin, int* argmax, hipStream_t st) {
     if (B == 0) return hipSuccess;
@@ -105,6 +156,20 @@ hipError_t launch_pool_bwd(const float* gout, int C, const int* ptr, const int* 
     PoolSchemes s;
     s.n = ns;
     for (int i = 0; i < 4; ++i) s.code[i] = i < ns ? codes[i] : 0;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = (C % 8 == 0) && (lddx % 8 == 0) && (!gate || (ldgate % 4 == 0 && al16(gate))) && al16(gout) &&
+                     al16(dx) && al16(argmin) && al16(argmax);
+    if (vec) {
+        const long long total = (long long)N * (C / 8);
+        const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+        if (dx_lowp)
+            hipLaunchKernelGGL(segment_pool_bwd8_kernel<__bf16>, grid, block, 0, st, gout, C, ptr, batch, N, s, argmin,
+                               argmax, gate, ldgate, (__bf16*)dx, lddx);
+        else
+            hipLaunchKernelGGL(segment_pool_bwd8_kernel<float>, grid, block, 0, st, gout, C, ptr, batch, N, s, argmin,
+                               argmax, gate, ldgate, (float*)dx, lddx);
+        return hipGetLastError();
+    }
     const long long total = (long long)N * C;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (dx_lowp)

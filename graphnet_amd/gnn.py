@@ -84,6 +84,37 @@ def _unpad_cols(dW: Tensor, widths: Sequence[int], unit: int = 4) -> Tensor:
     return torch.cat(parts, dim=1)
 
 
+class _WeightBuffers:
+    """Persistent, zero-initialised buffers the packed (padded / transposed / bf16) copies of the weights
+    are written into each step.  Only the real block of a buffer is ever written, so the pad rows and
+    columns stay zero: packing a weight is one strided copy-with-cast instead of pad + cat + cast."""
+
+    def __init__(self) -> None:
+        self._b: dict = {}
+
+    def get(self, key, shape, dtype, device) -> Tensor:
+        t = self._b.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device:
+            t = torch.zeros(shape, dtype=dtype, device=device)
+            self._b[key] = t
+        return t
+
+
+def _packed(wb: _WeightBuffers, key, W: Tensor, dtype: torch.dtype, kunit: int = 32, koffs=None, widths=None) -> Tensor:
+    """``ops.pack_weight`` layout (``[ceil128(N)][sum ceil_kunit(width)]``) written into a persistent buffer.
+    ``widths``: column segments of W, each padded to ``kunit`` in the packed K axis."""
+    N, K = int(W.shape[0]), int(W.shape[1])
+    widths = [K] if widths is None else list(widths)
+    kp = sum(ops.round_up(w, kunit) for w in widths)
+    buf = wb.get(key, (ops.round_up(N, 128), kp), dtype, W.device)
+    off = offp = 0
+    for w in widths:
+        buf[:N, offp: offp + w].copy_(W[:, off: off + w])
+        off += w
+        offp += ops.round_up(w, kunit)
+    return buf
+
+
 class _DynEdgeFunction(torch.autograd.Function):
     """x, graph -> node features after the post-processing MLP (optionally pooled).
 
@@ -108,6 +139,7 @@ class _DynEdgeFunction(torch.autograd.Function):
         act = ops.act_dtype(mode)                  # activations between kernels: fp32 / bf16 by mode
         x0 = ops.concat_globals(x, gv if G else None, batch, ops.round_up(F0, 32), dtype=act)
         xs: List[Tuple[Tensor, int]] = [(x0, F0)]
+        wb: _WeightBuffers = cfg["wbuf"]
         graphs, PQs, masks = [], [], []
         knn_coords: List[Tensor] = []          # fp32 coordinates each re-built graph was computed from
         plan = None
@@ -116,14 +148,14 @@ class _DynEdgeFunction(torch.autograd.Function):
             H1, H2 = int(W1.shape[0]), int(W2.shape[0])
             H1p = ops.round_up(H1, 32)
             Wa, Wb = W1[:, :Fin], W1[:, Fin:]
-            Wpq = torch.zeros((2 * H1p, Fin), dtype=torch.float32, device=x.device)
-            Wpq[:H1] = Wa - Wb
-            Wpq[H1p:H1p + H1] = Wb
-            bpq = torch.zeros(2 * H1p, dtype=torch.float32, device=x.device)
-            bpq[:H1] = b1
-            PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), ops.pack_weight(Wpq, [Fin], dt, ku), 2 * H1p, bias=bpq,
-                                out_lowp=lowp)
-            W2p = ops.pack_weight(W2, [H1], dt)
+            # packed [P ; Q] weight: rows 0..H1 = Wa - Wb, rows H1p..H1p+H1 = Wb (pads stay zero)
+            Wpq = wb.get(("Wpq", l), (ops.round_up(2 * H1p, 128), ops.round_up(Fin, ku)), dt, x.device)
+            torch.sub(Wa, Wb, out=Wpq[:H1, :Fin])
+            Wpq[H1p:H1p + H1, :Fin].copy_(Wb)
+            bpq = wb.get(("bpq", l), (2 * H1p,), torch.float32, x.device)
+            bpq[:H1].copy_(b1)
+            PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), Wpq, 2 * H1p, bias=bpq, out_lowp=lowp)
+            W2p = _packed(wb, ("W2p", l), W2, dt)
             if l + 1 < nconv:
                 cols = _subset_cols(cfg["features_subset"], H2)
                 if plan is None:
@@ -149,7 +181,8 @@ class _DynEdgeFunction(torch.autograd.Function):
         segs = xs
         for t, (W, b) in enumerate(post_p):
             # hidden post-MLP layers are activations (bf16 in bf16 mode); the last one feeds pooling: fp32
-            y = ops.linear_fwd(mode, _ksegs(segs), ops.pack_weight(W, [w for _, w in segs], dt, ku), int(W.shape[0]),
+            y = ops.linear_fwd(mode, _ksegs(segs), _packed(wb, ("post", t), W, dt, ku, widths=[w for _, w in segs]),
+                               int(W.shape[0]),
                                bias=b.contiguous(), relu=True, out_lowp=lowp and t + 1 < npost,
                                out_cols=ops.round_up(int(W.shape[0]), 8))
             ys.append((y, int(W.shape[0])))
@@ -179,6 +212,7 @@ class _DynEdgeFunction(torch.autograd.Function):
         conv_p = [params[4 * l: 4 * l + 4] for l in range(nconv)]
         post_p = [params[4 * nconv + 2 * t: 4 * nconv + 2 * t + 2] for t in range(npost)]
         xs, ys = ctx.xs, ctx.ys
+        wb: _WeightBuffers = cfg["wbuf"]
         N = int(xs[0][0].shape[0])
         dev = xs[0][0].device
         grads: List[Optional[Tensor]] = [None] * len(params)
@@ -205,18 +239,20 @@ class _DynEdgeFunction(torch.autograd.Function):
             grads[4 * nconv + 2 * t + 1] = dbt
             if t > 0:
                 yprev, Pprev = ys[t - 1]
-                dZ = ops.linear_fwd(mode, _ksegs([(dZ, Pt)]), ops.pack_weight(W.t(), [Pt], dt, ku), Pprev, gate=yprev,
+                dZ = ops.linear_fwd(mode, _ksegs([(dZ, Pt)]), _packed(wb, ("postT", t), W.t(), dt, ku), Pprev, gate=yprev,
                                     out_lowp=lowp, out_cols=ops.round_up(Pprev, 8))
             else:
                 # gradient w.r.t. the skip-cat input, segment 0 (the raw pulse features) excluded: nobody reads it
-                WT = torch.zeros((sum(seg_pad), Pt), dtype=torch.float32, device=dev)
-                off = 0
-                for s, (_, w) in enumerate(xs):
-                    WT[seg_off[s]: seg_off[s] + w] = W[:, off: off + w].t()
+                ncols = sum(seg_pad) - seg_off[1]
+                WT = wb.get(("catT",), (ops.round_up(ncols, 128), ops.round_up(Pt, ku)), dt, dev)
+                off = xs[0][1]
+                for s_ in range(1, len(xs)):
+                    w = xs[s_][1]
+                    r0 = seg_off[s_] - seg_off[1]
+                    WT[r0: r0 + w, :Pt].copy_(W[:, off: off + w].t())
                     off += w
                 dXcat = torch.empty((N, sum(seg_pad)), dtype=act, device=dev)
-                ops.linear_fwd(mode, _ksegs([(dZ, Pt)]), ops.pack_weight(WT[seg_off[1]:], [Pt], dt, ku),
-                               sum(seg_pad) - seg_off[1], out=dXcat[:, seg_off[1]:])
+                ops.linear_fwd(mode, _ksegs([(dZ, Pt)]), WT, ncols, out=dXcat[:, seg_off[1]:])
 
         # ---- DynEdgeConv layers, last first
         for l in reversed(range(nconv)):
@@ -229,7 +265,7 @@ class _DynEdgeFunction(torch.autograd.Function):
             dPQ = torch.empty((N, 2 * H1p), dtype=act, device=dev)
             dpre = torch.empty((max(g.rows, 1), H1p), dtype=dt, device=dev)
             dW2, db2 = ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, g_out, mask)   # also records h>0 bits
-            ops.edgeconv_bwd(mode, g, PQ, H1p, H2, g_out, mask, ops.pack_weight(W2.t(), [H2], dt), dpre,
+            ops.edgeconv_bwd(mode, g, PQ, H1p, H2, g_out, mask, _packed(wb, ("W2T", l), W2.t(), dt), dpre,
                              dPQ[:, :H1p])
             ops.edgeconv_dq_gather(mode, g, dpre, H1p, dPQ[:, H1p:])
             dWpq, dbpq = ops.linear_wgrad(mode, dPQ, 2 * H1p, _ksegs([(xin, Fin)]), with_bias=True)
@@ -241,10 +277,10 @@ class _DynEdgeFunction(torch.autograd.Function):
             grads[4 * l + 3] = db2
             if l > 0:
                 Wa, Wb = W1[:, :Fin], W1[:, Fin:]
-                WpqT = torch.zeros((Fin, 2 * H1p), dtype=torch.float32, device=dev)
-                WpqT[:, :H1] = (Wa - Wb).t()
-                WpqT[:, H1p:H1p + H1] = Wb.t()
-                ops.linear_fwd(mode, [(dPQ, 2 * H1p)], ops.pack_weight(WpqT, [2 * H1p], dt, ku), Fin,
+                WpqT = wb.get(("WpqT", l), (ops.round_up(Fin, 128), ops.round_up(2 * H1p, ku)), dt, dev)
+                torch.sub(Wa.t(), Wb.t(), out=WpqT[:Fin, :H1])
+                WpqT[:Fin, H1p:H1p + H1].copy_(Wb.t())
+                ops.linear_fwd(mode, [(dPQ, 2 * H1p)], WpqT, Fin,
                                out=dXcat[:, seg_off[l]: seg_off[l] + Fin], accum=True)
         return (None, None) + tuple(grads)
 
@@ -425,6 +461,13 @@ class DynEdge(GNN):
             cols = list(kc[0]) if isinstance(kc, list) and kc and isinstance(kc[0], (list, tuple)) else list(kc)
         return ops.knn_graph(x, cols, batch32, ptr32, k, strict=self._knn_strict)
 
+    def _weight_buffers(self) -> _WeightBuffers:
+        wb = self.__dict__.get("_wbuf")
+        if wb is None:
+            wb = _WeightBuffers()
+            self.__dict__["_wbuf"] = wb          # plain attribute: not a module / parameter / buffer
+        return wb
+
     def _kernel_params(self) -> List[Tensor]:
         ps: List[Tensor] = []
         for conv in self._conv_layers:
@@ -452,7 +495,7 @@ class DynEdge(GNN):
             "globals": gv, "globals_after": self._add_global_variables_after_pooling,
             "features_subset": self._features_subset, "k": self._nb_neighbours, "strict": self._knn_strict,
             "pools": None if self._skip_readout else self._global_pooling_schemes,
-            "want_trace": return_trace,
+            "want_trace": return_trace, "wbuf": self._weight_buffers(),
         }
         out = _DynEdgeFunction.apply(cfg, x, *self._kernel_params())
         if not self._skip_readout:
