@@ -39,7 +39,8 @@ __host__ __device__ constexpr int pitch4(int row_bytes) {
 
 constexpr int G2_ROWS = 64;
 
-template <int KSTEPS, int NW, typename OutT, bool GATE>
+// ACCUM (bf16 C only): C += result; the tile is staged in fp32 and rounded once after adding the old C.
+template <int KSTEPS, int NW, typename OutT, bool GATE, bool ACCUM>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_v2_kernel(
     const __bf16* __restrict__ A, long long lda, int M, int Kw,          // A rows: Kw real columns (% 8 == 0)
     const __bf16* __restrict__ Wp, int Kp, int Npad, int N,               // Wp: [Npad][Kp] packed weights
@@ -50,7 +51,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_v2_kernel(
     constexpr int KB = KSTEPS * 32;                      // bytes of one A row in LDS
     constexpr int AP = pitch4(KB);
     constexpr int CW = NW * 32;                          // columns of one population
-    constexpr int SP = pitch4(CW * (int)sizeof(OutT));
+    constexpr int STB = ACCUM ? 4 : (int)sizeof(OutT);  // bytes of a staged element
+    constexpr int SP = pitch4(CW * STB);
+    static_assert(!ACCUM || sizeof(OutT) == 2, "accumulate variant: bf16 C");
     constexpr int ACH = KSTEPS * 2;                      // 16-byte chunks per A row
     constexpr int ACPT = (G2_ROWS * ACH + NT - 1) / NT;  // ... per thread
     constexpr int OEL = 16 / (int)sizeof(OutT);          // output elements per 16-byte chunk
@@ -143,18 +146,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_v2_kernel(
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const f32x16& acc = rb ? acc1 : acc0;
-            unsigned char* srow = &Stage[(rb * 32 + r) * SP + (wave * 32 + 4 * h) * sizeof(OutT)];
+            unsigned char* srow = &Stage[(rb * 32 + r) * SP + (wave * 32 + 4 * h) * STB];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(&Bias[wave * 32 + 8 * g + 4 * h]);
                 const float v0 = fmaxf(acc[4 * g + 0] + bv[0], lo), v1 = fmaxf(acc[4 * g + 1] + bv[1], lo);
                 const float v2 = fmaxf(acc[4 * g + 2] + bv[2], lo), v3 = fmaxf(acc[4 * g + 3] + bv[3], lo);
-                if constexpr (sizeof(OutT) == 2) {
+                if constexpr (STB == 2) {
                     typedef unsigned int u32x2_v __attribute__((ext_vector_type(2)));
                     const u32x2_v pk = {pk2(v0, v1), pk2(v2, v3)};
-                    *reinterpret_cast<u32x2_v*>(srow + 8 * g * sizeof(OutT)) = pk;
+                    *reinterpret_cast<u32x2_v*>(srow + 8 * g * STB) = pk;
                 } else {
-                    *reinterpret_cast<f32x4*>(srow + 8 * g * sizeof(OutT)) = (f32x4){v0, v1, v2, v3};
+                    *reinterpret_cast<f32x4*>(srow + 8 * g * STB) = (f32x4){v0, v1, v2, v3};
                 }
             }
         }
@@ -162,7 +165,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_v2_kernel(
         __syncthreads();                                  // staging tile + next A tile complete
 
         // optional gate rows of this tile: all loads first, so that none is consumed after a store
-        u32x4 greg[GATE ? OCPT : 1];
+        u32x4 greg[(GATE || ACCUM) ? OCPT : 1];          // gate rows, or the old C rows (never both)
+        static_assert(!(GATE && ACCUM), "gate and accumulate are not combined");
+        if constexpr (ACCUM) {
+#pragma unroll
+            for (int i = 0; i < OCPT; ++i) {
+                const int id = tid + NT * i;
+                const int row = id / OCH, c = id % OCH;
+                const long long m = (long long)tile * G2_ROWS + row;
+                const int col = col0 + c * OEL;
+                const bool ok = id < G2_ROWS * OCH && m < M && col < N;
+                greg[i] = *reinterpret_cast<const u32x4*>(C + (ok ? m * ldc + col : 0));
+            }
+        }
         if constexpr (GATE) {
 #pragma unroll
             for (int i = 0; i < OCPT; ++i) {
@@ -181,7 +196,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_v2_kernel(
             const long long m = (long long)tile * G2_ROWS + row;
             const int col = col0 + c * OEL;
             if (id < G2_ROWS * OCH && m < M && col < N) {
-                u32x4 v = *reinterpret_cast<const u32x4*>(&Stage[row * SP + c * 16]);
+                u32x4 v;
+                if constexpr (ACCUM) {
+                    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(&Stage[row * SP + c * 32]);
+                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(&Stage[row * SP + c * 32 + 16]);
+                    const float nv[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned int ow = greg[i][w];
+                        const float o0 = __builtin_bit_cast(float, ow << 16), o1 = __builtin_bit_cast(float, ow & 0xffff0000u);
+                        v[w] = pk2(o0 + nv[2 * w], o1 + nv[2 * w + 1]);
+                    }
+                } else {
+                    v = *reinterpret_cast<const u32x4*>(&Stage[row * SP + c * 16]);
+                }
                 if constexpr (GATE && sizeof(OutT) == 2) {
                     // bf16 gate > 0  <=>  its 16 bits, as a signed integer, > 0 (+0 / -0 / negatives excluded)
 #pragma unroll
@@ -207,7 +235,7 @@ static bool g2_enabled() {
 }
 int device_cus();
 
-template <int KSTEPS, int NW, typename OutT>
+template <int KSTEPS, int NW, typename OutT, bool ACCUM = false>
 static hipError_t g2_launch(const void* A, long long lda, int M, int Kw, const void* Wp, int Kp, int Npad, int N,
                             const float* bias, const void* gate, long long ldgate, int relu, void* C, long long ldc,
                             hipStream_t st) {
@@ -218,15 +246,20 @@ static hipError_t g2_launch(const void* A, long long lda, int M, int Kw, const v
     if (slots < P) slots = P;
     const int rpx = slots / P;                           // row ranges per XCD
     const int nranges = 8 * rpx;
-    if (gate) {
+    if constexpr (ACCUM) {
+        if (gate) return hipErrorNotSupported;
+        hipLaunchKernelGGL((gemm_nt_v2_kernel<KSTEPS, NW, OutT, false, true>), dim3(8 * rpx * P), dim3(NW * 64), 0, st,
+                           (const __bf16*)A, lda, M, Kw, (const __bf16*)Wp, Kp, Npad, N, bias, (const __bf16*)gate,
+                           ldgate, relu, (OutT*)C, ldc, ntiles, nranges, P);
+    } else if (gate) {
         if constexpr (sizeof(OutT) == 2)
-            hipLaunchKernelGGL((gemm_nt_v2_kernel<KSTEPS, NW, OutT, true>), dim3(8 * rpx * P), dim3(NW * 64), 0, st,
+            hipLaunchKernelGGL((gemm_nt_v2_kernel<KSTEPS, NW, OutT, true, false>), dim3(8 * rpx * P), dim3(NW * 64), 0, st,
                                (const __bf16*)A, lda, M, Kw, (const __bf16*)Wp, Kp, Npad, N, bias, (const __bf16*)gate,
                                ldgate, relu, (OutT*)C, ldc, ntiles, nranges, P);
         else
             return hipErrorNotSupported;
     } else {
-        hipLaunchKernelGGL((gemm_nt_v2_kernel<KSTEPS, NW, OutT, false>), dim3(8 * rpx * P), dim3(NW * 64), 0, st,
+        hipLaunchKernelGGL((gemm_nt_v2_kernel<KSTEPS, NW, OutT, false, false>), dim3(8 * rpx * P), dim3(NW * 64), 0, st,
                            (const __bf16*)A, lda, M, Kw, (const __bf16*)Wp, Kp, Npad, N, bias, (const __bf16*)gate,
                            ldgate, relu, (OutT*)C, ldc, ntiles, nranges, P);
     }
@@ -236,7 +269,8 @@ static hipError_t g2_launch(const void* A, long long lda, int M, int Kw, const v
 // hipErrorNotSupported = outside the envelope (the caller uses the tiled kernel)
 hipError_t launch_gemm_nt_v2(const Segs& a, int M, const void* Wp, int Kp, int Npad, int N, const Epi& epi, void* C,
                              long long ldc, int out_lowp, hipStream_t st) {
-    if (!g2_enabled() || a.nseg != 1 || epi.accum || M == 0) return hipErrorNotSupported;
+    if (!g2_enabled() || a.nseg != 1 || M == 0) return hipErrorNotSupported;
+    if (epi.accum && (!out_lowp || epi.gate)) return hipErrorNotSupported;
     if (epi.gate && (!epi.gate_lowp || !out_lowp || (epi.ldgate & 7))) return hipErrorNotSupported;
     const int Kw = a.width[0];
     const int oel = out_lowp ? 8 : 4;
@@ -253,6 +287,14 @@ hipError_t launch_gemm_nt_v2(const Segs& a, int M, const void* Wp, int Kp, int N
         if ((KS) * 16 > Kp) return hipErrorNotSupported;      /* the W slice reads KS k-steps */      \
         return g2_launch<KS, NWV, OT>(A, lda, M, Kw, Wp, Kp, Npad, N, epi.bias, epi.gate, epi.ldgate, \
                                       epi.relu, C, ldc, st);                                          \
+    }
+    if (epi.accum) {                                     // C (bf16) += ...: fp32 staging, 8-wave populations
+        if (wide) return hipErrorNotSupported;
+        if (ks <= 16) { if (16 * 16 > Kp) return hipErrorNotSupported;
+                        return g2_launch<16, 8, __bf16, true>(A, lda, M, Kw, Wp, Kp, Npad, N, epi.bias, epi.gate, epi.ldgate, epi.relu, C, ldc, st); }
+        if (ks <= 22) { if (22 * 16 > Kp) return hipErrorNotSupported;
+                        return g2_launch<22, 8, __bf16, true>(A, lda, M, Kw, Wp, Kp, Npad, N, epi.bias, epi.gate, epi.ldgate, epi.relu, C, ldc, st); }
+        return hipErrorNotSupported;
     }
     if (out_lowp) {
         if (!wide) {

@@ -51,14 +51,18 @@ __global__ __launch_bounds__(256) void knn_plan_kernel(const int* __restrict__ p
     if (threadIdx.x == 0) tile_ptr[B] = carry;
 }
 
-template <int KMAX>
+// DT: number of coordinates at compile time (3 = the usual x,y,z: the distance is 8 instructions), or 0 =
+// run-time D <= 8 (every dimension guarded by a select).
+template <int KMAX, int DT>
 __global__ __launch_bounds__(KNN_TILE) void knn_kernel(
-    const float* __restrict__ x, long long ldx, KnnCols cols, int D,
+    const float* __restrict__ x, long long ldx, KnnCols cols, int Drt,
     const int* __restrict__ ptr, const int* __restrict__ tile_ptr, int B, int N, int k, int strict,
     int* __restrict__ nbr, int* __restrict__ ovf)
 {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) float cand[KNN_DMAX][KNN_CH];
+    constexpr int DM = DT > 0 ? DT : KNN_DMAX;         // dimensions touched by the unrolled loops
+    const int D = DT > 0 ? DT : Drt;
     const int w = blockIdx.x;
     if (w >= tile_ptr[B]) return;
     int elo = 0, ehi = B;                       // largest e with tile_ptr[e] <= w  (empty events share a value)
@@ -73,9 +77,9 @@ __global__ __launch_bounds__(KNN_TILE) void knn_kernel(
     const bool active = q < hi;
     const float INF = __builtin_inff();
 
-    float qc[KNN_DMAX];
+    float qc[DM];
 #pragma unroll
-    for (int d = 0; d < KNN_DMAX; ++d) qc[d] = (active && d < D) ? x[(long long)q * ldx + cols.c[d]] : 0.0f;
+    for (int d = 0; d < DM; ++d) qc[d] = (active && d < D) ? x[(long long)q * ldx + cols.c[d]] : 0.0f;
     float bd[KMAX];
     int bj[KMAX];
 #pragma unroll
@@ -88,14 +92,14 @@ __global__ __launch_bounds__(KNN_TILE) void knn_kernel(
         for (int t = threadIdx.x; t < cn4; t += KNN_TILE) {
             const float* row = x + (long long)(c0 + min(t, cn - 1)) * ldx;
 #pragma unroll
-            for (int d = 0; d < KNN_DMAX; ++d)
+            for (int d = 0; d < DM; ++d)
                 if (d < D) cand[d][t] = t < cn ? row[cols.c[d]] : 3.0e38f;      // pad: d2 = inf, never taken
         }
         __syncthreads();
         for (int jl = 0; jl < cn4; jl += 4) {
-            float cd[KNN_DMAX][4];
+            float cd[DM][4];
 #pragma unroll
-            for (int d = 0; d < KNN_DMAX; ++d) {
+            for (int d = 0; d < DM; ++d) {
                 if (d < D) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(&cand[d][jl]);
                     cd[d][0] = v[0]; cd[d][1] = v[1]; cd[d][2] = v[2]; cd[d][3] = v[3];
@@ -106,11 +110,11 @@ __global__ __launch_bounds__(KNN_TILE) void knn_kernel(
                 const int j = c0 + jl + u;
                 float d2 = 0.0f;
 #pragma unroll
-                for (int d = 0; d < KNN_DMAX; ++d) {
+                for (int d = 0; d < DM; ++d) {
                     if (d < D) {
                         const float diff = cd[d][u] - qc[d];
                         const float sq = diff * diff;
-                        d2 = d2 + sq;
+                        d2 = d2 + sq;                    // 0 + sq first: same left-to-right sum as the oracle
                     }
                 }
                 // inactive lanes, the query itself (strict) and NaN/inf distances never enter the list
@@ -398,9 +402,19 @@ hipError_t launch_knn(const float* x, long long ldx, const int* cols, int D, con
     // upper bound of sum ceil(n_e/64) known without reading ptr on the host; surplus workgroups exit at once
     const long long tiles = (long long)N / KNN_TILE + B;
     dim3 grid((unsigned)tiles), block(KNN_TILE);
-    if (kk <= 9) hipLaunchKernelGGL(knn_kernel<9>, grid, block, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, k, strict, nbr, ovf);
-    else if (kk <= 17) hipLaunchKernelGGL(knn_kernel<17>, grid, block, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, k, strict, nbr, ovf);
-    else hipLaunchKernelGGL(knn_kernel<33>, grid, block, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, k, strict, nbr, ovf);
+#define GN_KNN_LAUNCH(KM)                                                                                       \
+    {                                                                                                           \
+        if (D == 3)                                                                                             \
+            hipLaunchKernelGGL((knn_kernel<KM, 3>), grid, block, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, k,  \
+                               strict, nbr, ovf);                                                               \
+        else                                                                                                    \
+            hipLaunchKernelGGL((knn_kernel<KM, 0>), grid, block, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, k,  \
+                               strict, nbr, ovf);                                                               \
+    }
+    if (kk <= 9) GN_KNN_LAUNCH(9)
+    else if (kk <= 17) GN_KNN_LAUNCH(17)
+    else GN_KNN_LAUNCH(33)
+#undef GN_KNN_LAUNCH
     return hipGetLastError();
 }
 

@@ -277,11 +277,15 @@ class _DynEdgeFunction(torch.autograd.Function):
             grads[4 * l + 3] = db2
             if l > 0:
                 Wa, Wb = W1[:, :Fin], W1[:, Fin:]
-                WpqT = wb.get(("WpqT", l), (ops.round_up(Fin, 128), ops.round_up(2 * H1p, ku)), dt, dev)
-                torch.sub(Wa.t(), Wb.t(), out=WpqT[:Fin, :H1])
-                WpqT[:Fin, H1p:H1p + H1].copy_(Wb.t())
-                ops.linear_fwd(mode, [(dPQ, 2 * H1p)], WpqT, Fin,
-                               out=dXcat[:, seg_off[l]: seg_off[l] + Fin], accum=True)
+                # d_in += dP . (Wa - Wb) + dQ . Wb as two K = H1p contractions (each weights-stationary) that
+                # accumulate into the skip-cat gradient of the producing layer
+                WpT = wb.get(("WpT", l), (ops.round_up(Fin, 128), ops.round_up(H1p, ku)), dt, dev)
+                WqT = wb.get(("WqT", l), (ops.round_up(Fin, 128), ops.round_up(H1p, ku)), dt, dev)
+                torch.sub(Wa.t(), Wb.t(), out=WpT[:Fin, :H1])
+                WqT[:Fin, :H1].copy_(Wb.t())
+                d_in = dXcat[:, seg_off[l]: seg_off[l] + Fin]
+                ops.linear_fwd(mode, [(dPQ[:, :H1p], H1p)], WpT, Fin, out=d_in, accum=True)
+                ops.linear_fwd(mode, [(dPQ[:, H1p:], H1p)], WqT, Fin, out=d_in, accum=True)
         return (None, None) + tuple(grads)
 
 

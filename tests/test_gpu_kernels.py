@@ -268,6 +268,21 @@ def test_weights_stationary_gemm_matches_tiled():
         assert rel_err(res["v1"][:, :N], ref) < 2e-2, (K, N, "tiled vs torch")
         assert torch.equal(res["v2"][:, :N], res["v1"][:, :N]), (K, N, "stationary vs tiled")
         assert res["v2"].dtype == (dt if lowp else torch.float32)
+    # accumulate into a bf16 view (input-gradient GEMMs): C = RNE(C_old + A.W^T), one rounding in both kernels
+    a = torch.randn(M, 352).bfloat16().to(DEV)
+    Wp = ops.pack_weight((torch.randn(256, 352) * 0.1).to(DEV), [352], dt, ops.gemm_kunit(mode))
+    base = torch.randn(M, 1056).bfloat16()
+    res = {}
+    for tag, flag in (("v2", "0"), ("v1", "1")):
+        os.environ["GN_DISABLE_V2"] = flag
+        c = base.clone().to(DEV)
+        ops.linear_fwd(mode, [(a, 352)], Wp, 256, out=c[:, 288:544], accum=True)
+        torch.cuda.synchronize()
+        res[tag] = c
+    os.environ["GN_DISABLE_V2"] = "0"
+    assert torch.equal(res["v2"], res["v1"])
+    assert torch.equal(res["v2"][:, :288].cpu(), base[:, :288]) and torch.equal(res["v2"][:, 544:].cpu(), base[:, 544:])
+    assert not torch.equal(res["v2"][:, 288:544].cpu(), base[:, 288:544])
 
 
 # ------------------------------------------------------------------------------ EdgeConv
