@@ -22,6 +22,7 @@
 // Envelope: bf16, K <= 8 (S = 8 slots), H1p in {128, 352}, H2 % 32 == 0 and <= 256 (bwd: == 256).
 // Anything else, the overflow rows, and f32 mode run the generic kernels of edgeconv.hip.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace gn {
 
@@ -215,14 +216,23 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
                 for (int c = 3; c >= 0; --c) {
                     float sum = 0.0f;
                     unsigned int nib = 0;
+                    if (all_valid) {            // wave-uniform: almost every tile; no per-element selects
 #pragma unroll
-                    for (int qq = 3; qq >= 0; --qq) {
-                        const int q = 4 * c + qq;
-                        float x = acc[q];
-                        if (!all_valid) x = (((rb ? vrow1 : vrow0) >> acc_row(q, 0)) & 1u) ? x : -1.0f;
-                        sum += fmaxf(x, 0.0f);
-                        const float y = 0.0f - x;                                 // sign(y) = [x > 0]
-                        nib = __builtin_amdgcn_alignbit(nib, __builtin_bit_cast(unsigned int, y), 31);
+                        for (int qq = 3; qq >= 0; --qq) {
+                            const float x = acc[4 * c + qq];
+                            sum += fmaxf(x, 0.0f);
+                            const float y = 0.0f - x;                             // sign(y) = [x > 0]
+                            nib = __builtin_amdgcn_alignbit(nib, __builtin_bit_cast(unsigned int, y), 31);
+                        }
+                    } else {
+#pragma unroll
+                        for (int qq = 3; qq >= 0; --qq) {
+                            const int q = 4 * c + qq;
+                            const float x = (((rb ? vrow1 : vrow0) >> acc_row(q, 0)) & 1u) ? acc[q] : -1.0f;
+                            sum += fmaxf(x, 0.0f);
+                            const float y = 0.0f - x;
+                            nib = __builtin_amdgcn_alignbit(nib, __builtin_bit_cast(unsigned int, y), 31);
+                        }
                     }
                     sums[c] = sum;
                     pack = (pack << 4) | nib;
