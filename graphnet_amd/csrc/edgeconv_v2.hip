@@ -455,6 +455,13 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
 // =============================================================================== backward (dh, dP, dpre)
 // One wave per 32-column block of dh: NB1 = 11 -> an 11-wave (704-thread) workgroup, 3 waves on
 // three SIMDs (VGPR budget 168): W2^T slice 64 + accumulators 32 + staging.  NB1 = 4 -> 8 waves.
+// The kernel is VALU-bound, so the epilogue is laid out for few instructions per element:
+//   * MFMA operands are swapped (W2^T is the "A" operand): a lane holds ONE edge row and 4 consecutive
+//     columns per register group -> one h-bit word per row block, bfe + and per element, packed
+//     converts, 8-byte LDS writes of the dpre tile;
+//   * the slot sums dP[centre] = sum_slots dpre are a second, tiny MFMA: dpre^T (hardware-transposed
+//     LDS reads of the wave's own staged block) times a 0/1 slot-selection matrix, instead of 32 adds
+//     and cross-lane shuffles per lane.  (dP thus sums the bf16-rounded dpre rows: <= 1.5 bf16 ulp.)
 template <int NB1>   // H1p = 32 * NB1, H2 == 256
 __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
     EdgeGraph g, const __bf16* __restrict__ gout, long long ldg, const unsigned char* __restrict__ maskB,
@@ -466,7 +473,7 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
     constexpr int K = NB1 * 32;                    // output width (H1p)
     constexpr int K2 = 256, KS2 = K2 / 16;         // contraction (H2)
     constexpr int DP = K2 * 2 + 16;                // dm tile pitch (b128 reads)
-    constexpr int SP = K * 2 + 16;                 // dpre staging pitch
+    constexpr int SP = tr_pitch(K * 2);            // dpre staging pitch (ds_read_b64_tr_b16 conflict-free)
     constexpr int HBW = (V2_ROWS * NB1 + NT - 1) / NT;   // hbits words per thread
     __shared__ __attribute__((aligned(16))) unsigned char Ds[2][V2_ROWS * DP];
     __shared__ __attribute__((aligned(16))) unsigned int Hb[2][V2_ROWS * NB1];
@@ -552,6 +559,7 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
     __syncthreads();
 
     const int srow = tid / NB1, sc0 = tid % NB1;
+    unsigned int dp_pk[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
     int buf = 0;
     for (; tile < tile_end; ++tile, buf ^= 1) {
         GN_V2_LOAD_DM(tile + 1);
@@ -561,50 +569,77 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
             zero_acc(a0); zero_acc(a1);
             const unsigned char* p0 = &Ds[buf][r * DP + h * 16];
             const unsigned char* p1 = p0 + 32 * DP;
-            bf16x8 f0 = *reinterpret_cast<const bf16x8*>(p0);
-            bf16x8 f1 = *reinterpret_cast<const bf16x8*>(p1);
 #pragma unroll
             for (int s = 0; s < KS2; ++s) {
-                bf16x8 n0 = f0, n1 = f1;
-                if (s + 1 < KS2) {
-                    n0 = *reinterpret_cast<const bf16x8*>(p0 + (s + 1) * 32);
-                    n1 = *reinterpret_cast<const bf16x8*>(p1 + (s + 1) * 32);
-                }
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, wa[s], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, wa[s], a1, 0, 0, 0);
-                f0 = n0; f1 = n1;
+                const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(p0 + s * 32);
+                const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(p1 + s * 32);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s], f0, a0, 0, 0, 0);    // a[n][row]
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s], f1, a1, 0, 0, 0);
             }
 
-            // ---- epilogue: (.) [h > 0], slot sums -> dP, dpre tile -> LDS staging
-            const long long c0t = (long long)tile * (V2_ROWS / S);
+            // ---- epilogue: (.) [h > 0] -> dpre tile in LDS; lane = edge row r of the row block,
+            //      registers 4g..4g+3 = columns 8g + 4h + (0..3) of this wave's 32-column block
             const int nb = wave;
-            const int col = nb * 32 + r;
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const f32x16& acc = rb ? a1 : a0;
+                const int rl = rb * 32 + r;
+                const unsigned int wsh = Hb[buf][rl * NB1 + nb] >> (4 * h);
+                unsigned char* srow = &Stage[rl * SP + (nb * 32 + 4 * h) * 2];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float sum = 0.0f;
+                for (int gq = 0; gq < 4; ++gq) {
+                    float d[4];
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const int q = 4 * c + qq;
-                        const int rl = rb * 32 + acc_row(q, h);
-                        const unsigned int word = Hb[buf][rl * NB1 + nb];
-                        const int mk = __builtin_amdgcn_sbfe((int)(word >> r), 0, 1);      // 0 / -1
-                        const float av = acc[q];   // NB: never __builtin_bit_cast a vector ELEMENT lvalue (reads element 0)
-                        const float d = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, av) & (unsigned int)mk);
-                        sum += d;
-                        *reinterpret_cast<__bf16*>(&Stage[rl * SP + col * 2]) = (__bf16)d;
+                    for (int j = 0; j < 4; ++j) {
+                        const float av = acc[4 * gq + j];          // copy the element before any bit_cast
+                        int m;                                     // 0 / -1 from bit 8gq+j (v_bfe_i32: one op)
+                        m = __builtin_amdgcn_sbfe((int)wsh, 8 * gq + j, 1);
+                        d[j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, av) & (unsigned int)m);
                     }
-                    sum += __shfl_xor(sum, 32);
-                    const long long centre = c0t + rb * 4 + c;
-                    if ((c >> 1) == h && centre < g.N) dP[centre * ldp + col] = (__bf16)sum;
+                    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                    const u32x2_t pk = {pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
+                    *reinterpret_cast<u32x2_t*>(srow + 16 * gq) = pk;
                 }
+            }
+            // ---- slot sums on the matrix core: dP^T[n][c] = sum_rows dpre[row][n] * [row / 8 == c]
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // own LDS writes before own reads
+            f32x16 a2;
+            zero_acc(a2);
+            {
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                const int g4 = lane >> 4, li = lane & 15;
+                const unsigned char* tb = &Stage[(8 * (g4 >> 1) + (li >> 2)) * SP + (16 * (g4 & 1) + 4 * (li & 3)) * 2 + nb * 64];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (16 * s4) * SP));
+                    const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (16 * s4 + 4) * SP));
+                    const s16x8 dt = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    // rows 16*s4 + 8h .. +7 all belong to centre 2*s4 + h of the tile
+                    const unsigned int one2 = (r == 2 * s4 + h) ? 0x3f803f80u : 0u;      // two bf16 ones
+                    const u32x4 sel = {one2, one2, one2, one2};
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dt), __builtin_bit_cast(bf16x8, sel), a2, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {                           // lane r < 8 holds centre r of the tile
+                dp_pk[gq][0] = pack_bf16x2(a2[4 * gq + 0], a2[4 * gq + 1]);
+                dp_pk[gq][1] = pack_bf16x2(a2[4 * gq + 2], a2[4 * gq + 3]);
             }
         }
         // The next tile's operands go to LDS BEFORE this tile's dpre stores are issued: vmcnt retires in
         // order, so consuming those loads after the stores would wait for the stores' write acks every tile.
         GN_V2_WRITE_DM(buf ^ 1);
+        if (wave_on && r < 8) {                           // dP rows of the tile's 8 centres (after the prefetch is consumed)
+            const long long centre = (long long)tile * (V2_ROWS / S) + r;
+            if (centre < g.N) {
+                typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const u32x2_t v = {dp_pk[gq][0], dp_pk[gq][1]};
+                    *reinterpret_cast<u32x2_t*>(dP + centre * ldp + wave * 32 + 8 * gq + 4 * h) = v;
+                }
+            }
+        }
         __syncthreads();                                  // staging tile + next dm tile complete
 
         // cooperative store of the dpre tile: NB1 threads per row, 4 chunks of 16 bytes each at a fixed
