@@ -527,10 +527,28 @@ __global__ __launch_bounds__(256) void dq_gather_kernel(const T* __restrict__ dp
 #pragma unroll
                 for (int c = 0; c < 8; ++c) acc[c] += v[u][c];       // + 0.0f for the masked rows: exact
         }
+    } else if (deg <= 16384) {
+        // hub node: its list was sorted by rev_sort_kernel (graph.hip) -> stream it, 8 rows in flight
+        int t = 0;
+        for (; t + 8 <= deg; t += 8) {
+            float v[8][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dq_row_load<T>(dpre + (long long)rev_rows[lo + t + u] * H1p, col, ok, v[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] += v[u][c];
+        }
+        for (; t < deg; ++t) {
+            float v[8];
+            dq_row_load<T>(dpre + (long long)rev_rows[lo + t] * H1p, col, ok, v);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] += v[c];
+        }
     } else {
         int last = -1;
         for (int t = lo; t < hi; ++t) {
-            // next row id in ascending order: min over entries > last
+            // beyond the sort capacity: next row id in ascending order = min over entries > last (O(deg^2/64))
             int best = 0x7fffffff;
             for (int e = lo + lane; e < hi; e += 64) {
                 const int r = rev_rows[e];

@@ -263,6 +263,47 @@ __global__ __launch_bounds__(256) void rev_fill(const int* __restrict__ nbr, int
     }
 }
 
+// The in-edge lists are filled with atomics (arbitrary order).  The dQ gather sums rows in ascending row
+// id (fixed order -> reproducible): lists of <= 64 entries are ordered by the gathering wave itself, longer
+// ones (hub pulses: many pulses on one DOM share coordinates, so the lowest-index ones are everybody's
+// neighbours) are sorted here once per graph, in LDS, one workgroup per hub node.
+constexpr int REV_SORT_MIN = 64;          // lists longer than this are sorted by rev_sort_kernel
+constexpr int REV_SORT_CAP = 16384;       // ... up to this many entries (64 KB of LDS)
+__global__ __launch_bounds__(256) void rev_find_hubs(const int* __restrict__ rev_ptr, int N, int* __restrict__ hubs,
+                                                     int* __restrict__ nhubs) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const int d = rev_ptr[j + 1] - rev_ptr[j];
+    if (d > REV_SORT_MIN && d <= REV_SORT_CAP) hubs[atomicAdd(nhubs, 1)] = j;
+}
+__global__ __launch_bounds__(256) void rev_sort_kernel(const int* __restrict__ rev_ptr, const int* __restrict__ hubs,
+                                                       const int* __restrict__ nhubs, int* __restrict__ rev_rows) {
+    __shared__ int buf[REV_SORT_CAP];
+    const int n = *nhubs;
+    for (int t = blockIdx.x; t < n; t += gridDim.x) {
+        const int j = hubs[t];
+        const int lo = rev_ptr[j], d = rev_ptr[j + 1] - lo;
+        int P = 128;
+        while (P < d) P <<= 1;
+        for (int i = threadIdx.x; i < P; i += 256) buf[i] = i < d ? rev_rows[lo + i] : 0x7fffffff;
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                for (int i = threadIdx.x; i < P; i += 256) {
+                    const int p = i ^ jj;
+                    if (p > i) {
+                        const int a = buf[i], b = buf[p];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { buf[i] = b; buf[p] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = threadIdx.x; i < d; i += 256) rev_rows[lo + i] = buf[i];
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- edge_index <-> table
 __global__ __launch_bounds__(256) void table_degree(const int* __restrict__ nbr, const int* __restrict__ ovf,
                                                     int N, int K, int* __restrict__ deg) {
@@ -450,6 +491,11 @@ hipError_t launch_rev_build(const int* nbr, int N, int K, int S, const int* ovf_
     e = hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)N, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rev_fill, dim3(cdiv(rows, 256)), dim3(256), 0, st, nbr, N, K, S, ovf_src, ovf_cnt, rev_ptr, cursor, rev_rows);
+    // hub nodes (in-degree > 64): sort their lists once; `cursor` (free now) holds the hub list, tmp[0] its length
+    e = hipMemsetAsync(tmp, 0, sizeof(int), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rev_find_hubs, dim3(cdiv(N, 256)), dim3(256), 0, st, rev_ptr, N, cursor, tmp);
+    hipLaunchKernelGGL(rev_sort_kernel, dim3(N < 1024 ? N : 1024), dim3(256), 0, st, rev_ptr, cursor, tmp, rev_rows);
     return hipGetLastError();
 }
 

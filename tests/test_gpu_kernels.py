@@ -129,6 +129,43 @@ def test_reverse_adjacency(oracle):
         assert sorted(rr[rp[j]:rp[j + 1]].tolist()) == sorted(exp[j])
 
 
+@pytest.mark.parametrize("name,mode", [("fp32", 0), ("bf16", 1)])
+def test_dq_gather_hub_nodes(oracle, name, mode):
+    """Hub pulses (many pulses on one DOM -> the lowest-index ones are everybody's neighbours) have in-edge
+    lists far longer than a wave: those lists are sorted at graph build (ascending row id) and the gather
+    must still equal a plain index_add in ascending row order, twice bit-identically."""
+    from graphnet_amd import ops
+    b = _batch(30, seed=21)
+    x = b.x.clone()
+    ev = int((b.ptr[1:] - b.ptr[:-1]).argmax())
+    lo, hi = int(b.ptr[ev]), int(b.ptr[ev + 1])
+    assert hi - lo > 150
+    x[lo:lo + 150, :3] = x[lo, :3]              # 150 pulses on one DOM
+    ptr32, batch32 = _csr(b)
+    t = ops.knn_graph(x.to(DEV), [0, 1, 2], batch32, ptr32, 8)
+    t.build_reverse()
+    rp, rr = t.rev_ptr.cpu().numpy(), t.rev_rows.cpu().numpy()
+    deg = rp[1:] - rp[:-1]
+    assert deg.max() > 100
+    hub = int(deg.argmax())
+    assert np.all(np.diff(rr[rp[hub]:rp[hub + 1]]) > 0), "hub list sorted ascending"
+    dt = ops.act_dtype(mode)
+    torch.manual_seed(9)
+    H1p = 352
+    dpre = torch.randn(t.rows, H1p).to(dt)
+    dQ = torch.zeros(t.N, H1p, dtype=dt, device=DEV)
+    ops.edgeconv_dq_gather(mode, t, dpre.to(DEV), H1p, dQ)
+    dQ2 = torch.zeros_like(dQ)
+    ops.edgeconv_dq_gather(mode, t, dpre.to(DEV), H1p, dQ2)
+    assert torch.equal(dQ, dQ2)
+    ref = torch.zeros(t.N, H1p, dtype=torch.float64)
+    for j in range(t.N):
+        rows = torch.from_numpy(rr[rp[j]:rp[j + 1]].astype(np.int64))
+        if len(rows):
+            ref[j] = dpre[rows].double().sum(0)
+    assert rel_err(dQ, ref) < (1e-5 if mode == 0 else 1e-2)
+
+
 # ------------------------------------------------------------------------------ globals
 def test_graph_globals(oracle):
     from graphnet_amd import ops
