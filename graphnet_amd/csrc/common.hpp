@@ -180,7 +180,7 @@ struct EdgeGraph {
 
 // Layout of the opaque "saved for backward" buffer of one EdgeConv layer (bytes):
 //   words : uint32 [(N*S + N)][ceil(H2/32)]  relu bits, row-major   (generic kernels; overflow rows)
-//   maskB : uint8  [N][H2]                   slot bytes              (persistent v2 kernels)
+//   maskB : uint8 / uint16 [N][H2]           slot masks, S = 8 / 16 bits (persistent v2 kernels)
 //   hbits : uint8  [N*S][H1p/8] (+16 slack)  h > 0 bits              (persistent v2 kernels)
 struct SavedLayout { long long off_words, off_maskB, off_hbits, total; };
 inline SavedLayout saved_layout(long long N, int S, int H1p, int H2) {
@@ -188,7 +188,7 @@ inline SavedLayout saved_layout(long long N, int S, int H1p, int H2) {
     SavedLayout L;
     L.off_words = 0;
     L.off_maskB = up((N * S + N) * ((H2 + 31) / 32) * 4);
-    L.off_hbits = L.off_maskB + up(N * H2);
+    L.off_hbits = L.off_maskB + up(N * H2 * (S > 8 ? 2 : 1));
     L.total = L.off_hbits + up(N * S * (H1p / 8) + 16);
     return L;
 }

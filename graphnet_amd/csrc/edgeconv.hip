@@ -601,7 +601,7 @@ hipError_t launch_edge_bwd_v2(const EdgeGraph& g, int H1p, int H2, const void* g
                               const unsigned char* maskB, const unsigned char* hbits, const void* W2Tp, int H2p,
                               void* dpre, void* dP, long long ldp, int num_cus, hipStream_t st);
 bool edge_v2_shape_ok(int K, int H1p, int H2);
-int edge_dw2_v2_parts(int N, int H1p, int num_cus);
+int edge_dw2_v2_parts(int N, int K, int H1p, int num_cus);
 constexpr int DW2_OVF_SPLITS = 8;
 
 int device_cus() {
@@ -703,7 +703,7 @@ hipError_t launch_edge_bwd(int mode, const EdgeGraph& g, const void* PQ, int H1p
 // reduces them in fixed order (launch_reduce_slabs in gemm.hip).
 int edge_dw2_slabs(int mode, int N, int K, int H1p, int H2) {
     const int S_ = edge_slots(K);
-    if (mode == 1 && v2_enabled() && edge_v2_shape_ok(K, H1p, H2)) return edge_dw2_v2_parts(N, H1p, device_cus()) + DW2_OVF_SPLITS;
+    if (mode == 1 && v2_enabled() && edge_v2_shape_ok(K, H1p, H2)) return edge_dw2_v2_parts(N, K, H1p, device_cus()) + DW2_OVF_SPLITS;
     return (int)edge_dw2_splits((long long)N * S_ + N);
 }
 
@@ -736,7 +736,7 @@ hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p
         return edge_dw2_t<__bf16>(g, PQ, H1p, H1, H2, gout, ldg, words, 0, main_rows + g.N, slab, db2_part,
                                   edge_dw2_slabs(mode, g.N, g.K, H1p, H2), st);
     // persistent kernel for the table rows (also writes hbits), generic kernel for the overflow rows
-    const int parts = edge_dw2_v2_parts(g.N, H1p, device_cus());
+    const int parts = edge_dw2_v2_parts(g.N, g.K, H1p, device_cus());
     hipError_t e = launch_edge_dw2_v2(g, PQ, H1p, H1, H2, gout, ldg, sb + L.off_maskB, sb + L.off_hbits, slab, db2_part,
                                       device_cus(), st);
     if (e != hipSuccess) return e;

@@ -33,7 +33,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int V2_ROWS = 64;     // edge rows per tile = 8 centres x 8 slots
+constexpr int V2_ROWS = 64;     // edge rows per tile = 64 / S centres x S slots (S = 8 or 16 slots per centre)
 constexpr int V2_THREADS = 512;
 
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
@@ -76,7 +76,7 @@ __device__ __forceinline__ unsigned int nonzero_bits_bf16x8(u32x4 o) {
         long long row__ = (long long)(tile_) * V2_ROWS + grow;                                        \
         const bool inr__ = ((tile_) < ntiles) && (row__ < main_rows);                                 \
         row__ = inr__ ? row__ : 0;                                                                    \
-        const int ii__ = (int)(row__ >> 3), sl__ = (int)(row__ & 7);                                  \
+        const int ii__ = (int)(row__ / S), sl__ = (int)(row__ % S);        /* S: power of two */      \
         const int slc__ = sl__ < kslots ? sl__ : 0;                                                   \
         (raw_) = g.nbr[(long long)ii__ * kslots + slc__];                                             \
         (ic_) = ii__;                                                                                 \
@@ -103,13 +103,15 @@ __device__ __forceinline__ unsigned int nonzero_bits_bf16x8(u32x4 o) {
     }
 
 // =============================================================================== forward
-template <int KSTEPS>
+// S = slots per centre (8 or 16); the slot mask of (centre, column) is S bits: maskB is uint8 / uint16 [N][H2].
+template <int KSTEPS, int S>
 __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
     EdgeGraph g, const __bf16* __restrict__ PQ, const __bf16* __restrict__ W2p, const float* __restrict__ b2,
     int H2, __bf16* __restrict__ out, long long ldo, float* __restrict__ coords, CoordCols ccols,
     unsigned char* __restrict__ maskB, int ntiles)
 {
-    constexpr int S = 8;
+    static_assert(S == 8 || S == 16, "8 or 16 slots per centre");
+    constexpr int NST = 16 / S;                    // centres stored per lane and 32-row block: 2 (S=8) / 1 (S=16)
     constexpr int K = KSTEPS * 16;                 // = H1p
     constexpr int ROWB = K * 2 + 16;               // LDS row pitch: conflict-free ds_read_b128
     constexpr int CHUNKS = K / 8;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
 #pragma unroll
         for (int q = 0; q < 16; ++q) { acc0[q] = bias; acc1[q] = bias; }
         float st_sum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        unsigned int st_msk = 0;
+        unsigned int st_msk = 0;                    // S=8: 4 bytes (rb, c2); S=16: 2 halfwords (rb)
         if (wave_on) {
             const unsigned char* a0 = &As[buf][r * ROWB + h * 16];
             const unsigned char* a1 = a0 + 32 * ROWB;
@@ -239,15 +241,27 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
                 }
                 const unsigned int other = __shfl_xor(pack, 32);
                 const unsigned int lo16 = h ? other : pack, hi16 = h ? pack : other;   // slots 0-3 / 4-7
-                // this lane stores centres c = 2h, 2h+1 of the row block; the stores themselves are issued
-                // at the end of the iteration (see below)
+                if constexpr (S == 8) {
+                    // this lane stores centres c = 2h, 2h+1 of the row block (stores issued at the end of the iteration)
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    const float mine = h ? sums[2 + cc] : sums[cc];
-                    const float theirs = h ? sums[cc] : sums[2 + cc];          // what the partner lane needs
-                    st_sum[rb][cc] = mine + __shfl_xor(theirs, 32);
-                    const int sh = 4 * (2 * h + cc);
-                    st_msk |= (((lo16 >> sh) & 0xFu) | (((hi16 >> sh) & 0xFu) << 4)) << (8 * (2 * rb + cc));
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const float mine = h ? sums[2 + cc] : sums[cc];
+                        const float theirs = h ? sums[cc] : sums[2 + cc];          // what the partner lane needs
+                        st_sum[rb][cc] = mine + __shfl_xor(theirs, 32);
+                        const int sh = 4 * (2 * h + cc);
+                        st_msk |= (((lo16 >> sh) & 0xFu) | (((hi16 >> sh) & 0xFu) << 4)) << (8 * (2 * rb + cc));
+                    }
+                } else {
+                    // 16 slots: centre cb of the block = register groups 2cb, 2cb+1 of both lane halves; slots
+                    // 0-3 / 8-11 live in half 0, 4-7 / 12-15 in half 1.  This lane stores centre cb = h.
+                    const float own0 = sums[0] + sums[1], own1 = sums[2] + sums[3];
+                    const float mine = h ? own1 : own0;
+                    const float theirs = h ? own0 : own1;
+                    st_sum[rb][0] = mine + __shfl_xor(theirs, 32);
+                    const int sh = 8 * h;
+                    const unsigned int m16 = ((lo16 >> sh) & 0xFu) | (((hi16 >> sh) & 0xFu) << 4) |
+                                             (((lo16 >> (sh + 4)) & 0xFu) << 8) | (((hi16 >> (sh + 4)) & 0xFu) << 12);
+                    st_msk |= m16 << (16 * rb);
                 }
             }
         }
@@ -267,11 +281,14 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) {
-                    const long long centre = c0t + rb * 4 + 2 * h + c2;
+                for (int c2 = 0; c2 < NST; ++c2) {
+                    const long long centre = c0t + rb * (32 / S) + NST * h + c2;
                     if (centre < g.N) {
                         out[centre * ldo + col] = (__bf16)st_sum[rb][c2];
-                        maskB[centre * H2 + col] = (unsigned char)(st_msk >> (8 * (2 * rb + c2)));
+                        if constexpr (S == 8)
+                            maskB[centre * H2 + col] = (unsigned char)(st_msk >> (8 * (2 * rb + c2)));
+                        else
+                            reinterpret_cast<unsigned short*>(maskB)[centre * H2 + col] = (unsigned short)(st_msk >> (16 * rb));
                         if (is_coord) coords[centre * 8 + coord_d] = st_sum[rb][c2];
                     }
                 }
@@ -292,13 +309,13 @@ __host__ __device__ constexpr int tr_pitch(int row_bytes) {
 // accumulator (32 x NBH*32 fp32 per wave) fits the 256-VGPR budget of 2 waves/SIMD: workgroup b
 // handles k1 blocks [kb0, kb0+nblk) (kb0 = (b % HALVES) * NBH) of the tile range b / HALVES, gathers
 // only those columns of h, and writes them into slab b / HALVES.
-template <int NB1, int NBH, int HALVES>   // H1p = 32 * NB1
+template <int NB1, int NBH, int HALVES, int S>   // H1p = 32 * NB1, S slots per centre
 __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
     EdgeGraph g, const __bf16* __restrict__ PQ, int H1, int H2,
     const __bf16* __restrict__ gout, long long ldg, const unsigned char* __restrict__ maskB,
     unsigned char* __restrict__ hbits, float* __restrict__ slab, float* __restrict__ db2_part, int ntiles)
 {
-    constexpr int S = 8;
+    static_assert(S == 8 || S == 16, "8 or 16 slots per centre");
     constexpr int K = NB1 * 32;
     constexpr int CHUNKS = K / 8;
     constexpr int NI = (NBH * 4 + 7) / 8;           // 16-byte chunks per thread (8 threads per row)
@@ -348,17 +365,19 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
             }                                                                                         \
         }                                                                                             \
     }
-    // A-side operands of one tile: per k-step s the lane needs g_out and the slot byte of centre
-    // (8*tile + 2s + h) at column n2; the four slot bytes are packed into one register
+    // A-side operands of one tile: k-step s covers 16 edge rows, lane half h their rows 8h..8h+7 = eight
+    // slots of ONE centre: centre 8*tile + 2s + h (S = 8) or centre 4*tile + s, slots 8h.. (S = 16).
+    // The lane needs g_out and those 8 slot bits at column n2; the four bytes are packed into one register
 #define GN_V2_LOAD_A(tile_, gv_, mv_)                                                                 \
     {                                                                                                 \
         (mv_) = 0u;                                                                                   \
         _Pragma("unroll") for (int s = 3; s >= 0; --s) {                                              \
-            const long long c__ = (long long)(tile_) * 8 + 2 * s + h;                                 \
+            const long long c__ = (S == 8) ? (long long)(tile_) * 8 + 2 * s + h : (long long)(tile_) * 4 + s; \
             const bool ok__ = (tile_) < ntiles && c__ < g.N && n2 < H2;                               \
             const long long cs__ = ok__ ? c__ : 0;                                                    \
             const float gl__ = (float)gout[cs__ * ldg + n2c];                                         \
-            const unsigned int ml__ = maskB[cs__ * H2 + n2c];                                         \
+            const unsigned int ml__ = (S == 8) ? (unsigned int)maskB[cs__ * H2 + n2c]                 \
+                                               : (unsigned int)maskB[(cs__ * H2 + n2c) * 2 + h];      \
             gv_[s] = ok__ ? gl__ : 0.0f;                                                              \
             (mv_) = ((mv_) << 8) | (ok__ ? ml__ : 0u);                                                \
         }                                                                                             \
@@ -462,13 +481,14 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
 //   * the slot sums dP[centre] = sum_slots dpre are a second, tiny MFMA: dpre^T (hardware-transposed
 //     LDS reads of the wave's own staged block) times a 0/1 slot-selection matrix, instead of 32 adds
 //     and cross-lane shuffles per lane.  (dP thus sums the bf16-rounded dpre rows: <= 1.5 bf16 ulp.)
-template <int NB1>   // H1p = 32 * NB1, H2 == 256
+template <int NB1, int S>   // H1p = 32 * NB1, H2 == 256, S slots per centre
 __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
     EdgeGraph g, const __bf16* __restrict__ gout, long long ldg, const unsigned char* __restrict__ maskB,
     const unsigned char* __restrict__ hbits, const __bf16* __restrict__ W2Tp,
     __bf16* __restrict__ dpre, __bf16* __restrict__ dP, long long ldp, int ntiles)
 {
-    constexpr int S = 8;
+    static_assert(S == 8 || S == 16, "8 or 16 slots per centre");
+    constexpr int CPT = V2_ROWS / S;               // centres per tile
     constexpr int NT = (NB1 > 8 ? NB1 : 8) * 64;   // threads
     constexpr int K = NB1 * 32;                    // output width (H1p)
     constexpr int K2 = 256, KS2 = K2 / 16;         // contraction (H2)
@@ -483,7 +503,7 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
     const int r = lane & 31, h = lane >> 5;
     const long long main_rows = (long long)g.N * S;
     const bool wave_on = wave < NB1;
-    const bool builder = wave < 8;                  // waves 0-7 build the dm tile (wave = centre)
+    const bool builder = wave < 8;                  // waves 0-7 build the dm tile
 
     // stationary W2^T slice: row n = 32*wave + r of W2Tp [.., K2]
     bf16x8 wa[KS2];
@@ -497,10 +517,13 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
         for (int s = 0; s < KS2; ++s) wa[s] = *reinterpret_cast<const bf16x8*>(wrow + s * 16);
     }
 
-    // dm build mapping: wave = centre of the tile, lane&31 = 8-column chunk, lane>>5 = slot half
-    const int bcl = wave & 7, bcc = lane & 31, bsh = lane >> 5;
+    // dm build mapping: lane&31 = 8-column chunk; S = 8: wave = centre, lane>>5 = slot half (4 slots);
+    // S = 16: wave>>1 = centre, (wave&1, lane>>5) = slot quarter (4 slots)
+    const int bcl = (S == 8) ? (wave & 7) : ((wave & 7) >> 1);
+    const int bcc = lane & 31;
+    const int bsh = (S == 8) ? (lane >> 5) : (((wave & 1) << 1) | (lane >> 5));
     u32x4 gw = {0u, 0u, 0u, 0u};                    // 8 bf16 of g_out[centre], as stored
-    unsigned int mlo = 0, mhi = 0;
+    u32x4 mq = {0u, 0u, 0u, 0u};                    // slot masks of those 8 columns: 8 bytes (S=8) / 8 halfwords (S=16)
     unsigned int hbw[HBW];
     bool dm_ok = false, hb_ok[HBW];
 // Loads only ISSUE here (addresses clamped in range); validity masks are applied in GN_V2_WRITE_DM, one
@@ -509,13 +532,17 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
 #define GN_V2_LOAD_DM(tile_)                                                                          \
     {                                                                                                 \
         if (builder) {                                                                                \
-            const long long c__ = (long long)(tile_) * 8 + bcl;                                       \
+            const long long c__ = (long long)(tile_) * CPT + bcl;                                     \
             dm_ok = (tile_) < ntiles && c__ < g.N;                                                    \
             const long long cs__ = dm_ok ? c__ : 0;                                                   \
             gw = *reinterpret_cast<const u32x4*>(gout + cs__ * ldg + bcc * 8);                        \
-            const unsigned int* mp__ = reinterpret_cast<const unsigned int*>(maskB + cs__ * K2 + bcc * 8); \
-            mlo = mp__[0];                                                                            \
-            mhi = mp__[1];                                                                            \
+            if constexpr (S == 8) {                                                                   \
+                const unsigned int* mp__ = reinterpret_cast<const unsigned int*>(maskB + cs__ * K2 + bcc * 8); \
+                mq[0] = mp__[0];                                                                      \
+                mq[1] = mp__[1];                                                                      \
+            } else {                                                                                  \
+                mq = *reinterpret_cast<const u32x4*>(maskB + (cs__ * K2 + bcc * 8) * 2);              \
+            }                                                                                         \
         }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < HBW; ++i) {                                             \
             const int w__ = tid + NT * i;                        /* word index in [64][NB1] */        \
@@ -529,20 +556,24 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
     {                                                                                                 \
         if (builder) {                                                                                \
             const u32x4 gw__ = gw;                                                                    \
-            const unsigned int okm__ = dm_ok ? 0x01010101u : 0u;                                      \
+            const unsigned int okm__ = dm_ok ? (S == 8 ? 0x01010101u : 0x00010001u) : 0u;             \
             _Pragma("unroll") for (int si = 0; si < 4; ++si) {                                        \
                 const int slot__ = 4 * bsh + si;                                                      \
-                const unsigned int flo__ = (mlo >> slot__) & okm__;                                   \
-                const unsigned int fhi__ = (mhi >> slot__) & okm__;                                   \
                 u32x4 dw__;                                                                           \
                 _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                    \
-                    const unsigned int f__ = jj < 2 ? flo__ : fhi__;                                  \
-                    const unsigned int sel__ = (jj & 1) ? 0x0c030c02u : 0x0c010c00u;                  \
-                    const unsigned int e__ = __builtin_amdgcn_perm(0u, f__, sel__);  /* {b,0,b',0} */ \
+                    unsigned int e__;                            /* {b, 0, b', 0}: bit per bf16 lane */ \
+                    if constexpr (S == 8) {                                                           \
+                        const unsigned int mw__ = jj < 2 ? mq[0] : mq[1];                             \
+                        const unsigned int f__ = (mw__ >> slot__) & okm__;                            \
+                        e__ = __builtin_amdgcn_perm(0u, f__, (jj & 1) ? 0x0c030c02u : 0x0c010c00u);   \
+                    } else {                                                                          \
+                        const unsigned int mw__ = mq[jj];        /* copy the element (no bit_cast) */ \
+                        e__ = (mw__ >> slot__) & okm__;                                               \
+                    }                                                                                 \
                     const s16x2 mk__ = (s16x2){0, 0} - __builtin_bit_cast(s16x2, e__);                \
                     dw__[jj] = gw__[jj] & __builtin_bit_cast(unsigned int, mk__);                     \
                 }                                                                                     \
-                *reinterpret_cast<u32x4*>(&Ds[buf_][(8 * bcl + slot__) * DP + bcc * 16]) = dw__;      \
+                *reinterpret_cast<u32x4*>(&Ds[buf_][(S * bcl + slot__) * DP + bcc * 16]) = dw__;      \
             }                                                                                         \
         }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < HBW; ++i) {                                             \
@@ -614,14 +645,15 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
                     const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (16 * s4) * SP));
                     const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (16 * s4 + 4) * SP));
                     const s16x8 dt = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    // rows 16*s4 + 8h .. +7 all belong to centre 2*s4 + h of the tile
-                    const unsigned int one2 = (r == 2 * s4 + h) ? 0x3f803f80u : 0u;      // two bf16 ones
+                    // rows 16*s4 + 8h .. +7 all belong to ONE centre of the tile: 2*s4 + h (S = 8) or s4 (S = 16)
+                    const int cen = (S == 8) ? 2 * s4 + h : s4;
+                    const unsigned int one2 = (r == cen) ? 0x3f803f80u : 0u;             // two bf16 ones
                     const u32x4 sel = {one2, one2, one2, one2};
                     a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dt), __builtin_bit_cast(bf16x8, sel), a2, 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {                           // lane r < 8 holds centre r of the tile
+            for (int gq = 0; gq < 4; ++gq) {                           // lane r < CPT holds centre r of the tile
                 dp_pk[gq][0] = pack_bf16x2(a2[4 * gq + 0], a2[4 * gq + 1]);
                 dp_pk[gq][1] = pack_bf16x2(a2[4 * gq + 2], a2[4 * gq + 3]);
             }
@@ -629,7 +661,7 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
         // The next tile's operands go to LDS BEFORE this tile's dpre stores are issued: vmcnt retires in
         // order, so consuming those loads after the stores would wait for the stores' write acks every tile.
         GN_V2_WRITE_DM(buf ^ 1);
-        if (wave_on && r < 8) {                           // dP rows of the tile's 8 centres (after the prefetch is consumed)
+        if (wave_on && r < CPT) {                         // dP rows of the tile's centres (after the prefetch is consumed)
             const long long centre = (long long)tile * (V2_ROWS / S) + r;
             if (centre < g.N) {
                 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -666,9 +698,10 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
 
 // =============================================================================== launchers
 // hipErrorNotSupported = shape outside the v2 envelope (caller falls back to the generic kernels)
-static inline int v2_tiles(const EdgeGraph& g) { return (int)(((long long)g.N * 8 + V2_ROWS - 1) / V2_ROWS); }
+int edge_slots(int K);
+static inline int v2_tiles(const EdgeGraph& g) { return (int)(((long long)g.N * edge_slots(g.K) + V2_ROWS - 1) / V2_ROWS); }
 bool edge_v2_shape_ok(int K, int H1p, int H2) {
-    return K <= 8 && H2 == 256 && (H1p == 128 || H1p == 352);
+    return K <= 16 && H2 == 256 && (H1p == 128 || H1p == 352);
 }
 
 hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
@@ -678,18 +711,19 @@ hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, const
     if (g.N == 0) return hipSuccess;
     const int ntiles = v2_tiles(g);
     const int grid = ntiles < num_cus ? ntiles : num_cus;
-    if (H1p == 128)
-        hipLaunchKernelGGL((edge_fwd_v2_kernel<8>), dim3(grid), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
-                           (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, coords, cc, maskB, ntiles);
-    else
-        hipLaunchKernelGGL((edge_fwd_v2_kernel<22>), dim3(grid), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
-                           (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, coords, cc, maskB, ntiles);
+#define GN_FWD_LAUNCH(KS, SS)                                                                              \
+    hipLaunchKernelGGL((edge_fwd_v2_kernel<KS, SS>), dim3(grid), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,  \
+                       (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, coords, cc, maskB, ntiles)
+    const bool s8 = edge_slots(g.K) == 8;
+    if (H1p == 128) { if (s8) GN_FWD_LAUNCH(8, 8); else GN_FWD_LAUNCH(8, 16); }
+    else { if (s8) GN_FWD_LAUNCH(22, 8); else GN_FWD_LAUNCH(22, 16); }
+#undef GN_FWD_LAUNCH
     return hipGetLastError();
 }
 
 // number of slabs (= tile-range parts) the dW2 kernel writes for N nodes
-int edge_dw2_v2_parts(int N, int H1p, int num_cus) {
-    const long long ntiles = ((long long)N * 8 + V2_ROWS - 1) / V2_ROWS;
+int edge_dw2_v2_parts(int N, int K, int H1p, int num_cus) {
+    const long long ntiles = ((long long)N * edge_slots(K) + V2_ROWS - 1) / V2_ROWS;
     const int halves = H1p == 352 ? 2 : 1;
     long long parts = num_cus / halves;
     if (parts > ntiles) parts = ntiles;
@@ -703,13 +737,14 @@ hipError_t launch_edge_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H
     if (!edge_v2_shape_ok(g.K, H1p, H2)) return hipErrorNotSupported;
     if (g.N == 0) return hipSuccess;
     const int ntiles = v2_tiles(g);
-    const int parts = edge_dw2_v2_parts(g.N, H1p, num_cus);
-    if (H1p == 128)
-        hipLaunchKernelGGL((edge_dw2_v2_kernel<4, 4, 1>), dim3(parts), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
-                           H1, H2, (const __bf16*)gout, ldg, maskB, hbits, slab, db2_part, ntiles);
-    else
-        hipLaunchKernelGGL((edge_dw2_v2_kernel<11, 6, 2>), dim3(parts * 2), dim3(V2_THREADS), 0, st, g,
-                           (const __bf16*)PQ, H1, H2, (const __bf16*)gout, ldg, maskB, hbits, slab, db2_part, ntiles);
+    const int parts = edge_dw2_v2_parts(g.N, g.K, H1p, num_cus);
+#define GN_DW2_LAUNCH(A, B, C, SS, GRID)                                                                    \
+    hipLaunchKernelGGL((edge_dw2_v2_kernel<A, B, C, SS>), dim3(GRID), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ, \
+                       H1, H2, (const __bf16*)gout, ldg, maskB, hbits, slab, db2_part, ntiles)
+    const bool s8 = edge_slots(g.K) == 8;
+    if (H1p == 128) { if (s8) GN_DW2_LAUNCH(4, 4, 1, 8, parts); else GN_DW2_LAUNCH(4, 4, 1, 16, parts); }
+    else { if (s8) GN_DW2_LAUNCH(11, 6, 2, 8, parts * 2); else GN_DW2_LAUNCH(11, 6, 2, 16, parts * 2); }
+#undef GN_DW2_LAUNCH
     return hipGetLastError();
 }
 
@@ -720,12 +755,13 @@ hipError_t launch_edge_bwd_v2(const EdgeGraph& g, int H1p, int H2, const void* g
     if (g.N == 0) return hipSuccess;
     const int ntiles = v2_tiles(g);
     const int grid = ntiles < num_cus ? ntiles : num_cus;
-    if (H1p == 128)
-        hipLaunchKernelGGL((edge_bwd_v2_kernel<4>), dim3(grid), dim3(512), 0, st, g, (const __bf16*)gout, ldg, maskB, hbits,
-                           (const __bf16*)W2Tp, (__bf16*)dpre, (__bf16*)dP, ldp, ntiles);
-    else
-        hipLaunchKernelGGL((edge_bwd_v2_kernel<11>), dim3(grid), dim3(704), 0, st, g, (const __bf16*)gout, ldg, maskB, hbits,
-                           (const __bf16*)W2Tp, (__bf16*)dpre, (__bf16*)dP, ldp, ntiles);
+#define GN_BWD_LAUNCH(NB, SS, THREADS)                                                                      \
+    hipLaunchKernelGGL((edge_bwd_v2_kernel<NB, SS>), dim3(grid), dim3(THREADS), 0, st, g, (const __bf16*)gout, ldg, \
+                       maskB, hbits, (const __bf16*)W2Tp, (__bf16*)dpre, (__bf16*)dP, ldp, ntiles)
+    const bool s8 = edge_slots(g.K) == 8;
+    if (H1p == 128) { if (s8) GN_BWD_LAUNCH(4, 8, 512); else GN_BWD_LAUNCH(4, 16, 512); }
+    else { if (s8) GN_BWD_LAUNCH(11, 8, 704); else GN_BWD_LAUNCH(11, 16, 704); }
+#undef GN_BWD_LAUNCH
     return hipGetLastError();
 }
 

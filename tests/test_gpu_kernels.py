@@ -430,10 +430,12 @@ def test_persistent_kernels_match_generic_kernels(oracle):
     import os
     from graphnet_amd import ops
     mode, dt = 1, torch.bfloat16
-    for (F, H1, H2, n_events) in ((256, 336, 256, 60), (32, 128, 256, 20)):
-        b, x3, x, mlp, ei = _edgeconv_case(oracle, k=8, F=F, H1=H1, H2=H2, n_events=n_events, seed=12)
+    # k <= 8 -> 8 slots per centre (uint8 slot masks), 9 <= k <= 16 -> 16 slots (uint16 masks)
+    for (kk, F, H1, H2, n_events) in ((8, 256, 336, 256, 60), (8, 32, 128, 256, 20), (16, 256, 336, 256, 40),
+                                      (11, 32, 128, 256, 20)):
+        b, x3, x, mlp, ei = _edgeconv_case(oracle, k=kk, F=F, H1=H1, H2=H2, n_events=n_events, seed=12)
         ptr32, batch32 = _csr(b)
-        g = ops.knn_graph(x3.to(DEV), [0, 1, 2], batch32, ptr32, 8)
+        g = ops.knn_graph(x3.to(DEV), [0, 1, 2], batch32, ptr32, kk)
         assert int(g.ovf_cnt.item()) > 0
         N, H1p = g.N, ops.round_up(H1, 32)
         W1, b1, W2, b2 = [p.detach().to(DEV) for p in (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)]
@@ -457,9 +459,15 @@ def test_persistent_kernels_match_generic_kernels(oracle):
             torch.cuda.synchronize()
             res[tag] = dict(out=out, dW2=dW2, db2=db2, dPQ=dPQ, dpre=dpre.float())
         os.environ["GN_DISABLE_V2"] = "0"
-        for k in ("dW2", "db2"):
-            assert rel_err(res["v2"][k], res["v1"][k]) < 1e-4, (F, H1, k)
-        for k in ("out", "dPQ"):                                 # bf16 tensors: equal up to one bf16 ulp
-            assert rel_err(res["v2"][k], res["v1"][k]) < 1e-2, (F, H1, k)
-        nrows = N * 8 + int(g.ovf_cnt.item())
-        assert rel_err(res["v2"]["dpre"][:nrows], res["v1"]["dpre"][:nrows]) < 1e-2, (F, H1, "dpre")
+        # The two kernel families accumulate in different orders, so a pre-activation within rounding of 0
+        # can get a different relu bit (a handful of elements per million); gates: Frobenius-norm error, and
+        # the fraction of elements that differ by more than 1 % of the tensor's max.
+        def close(a, c, what):
+            d = (a.float() - c.float()).abs()
+            frac = float((d > 1e-2 * c.float().abs().max()).float().mean())
+            tol = 5e-3 if a.dtype == torch.bfloat16 or what == "dpre" else 2e-3     # bf16: one-ulp noise
+            assert norm_err(a, c) < tol and frac < 1e-4, (kk, F, H1, what, norm_err(a, c), frac)
+        for k in ("dW2", "db2", "out", "dPQ"):
+            close(res["v2"][k], res["v1"][k], k)
+        nrows = N * g.S + int(g.ovf_cnt.item())
+        close(res["v2"]["dpre"][:nrows], res["v1"]["dpre"][:nrows], "dpre")
