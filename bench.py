@@ -40,6 +40,36 @@ def build_model(dtype: str):
     return m
 
 
+def measured_peaks(dev) -> dict:
+    """Yardsticks measured in this run: a large library bf16 GEMM (hipBLASLt through
+    torch.matmul) and a device-to-device copy.  Not used as denominators: `roofline.peak` stays the
+    MI355X_MICROARCH.md figure (2.5 PFLOP/s dense bf16, 8 TB/s HBM)."""
+    n = 8192
+    a = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+    torch.matmul(a, b)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(10):
+        torch.matmul(a, b)
+    e1.record()
+    torch.cuda.synchronize()
+    gemm = 10 * 2.0 * n ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy = 10 * 2.0 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9          # read + write bytes
+    return {"library_bf16_gemm_tflops": gemm, "hbm_copy_gbs": copy,
+            "note": "8192^3 bf16 torch.matmul; 1 GiB device copy (read+write bytes)"}
+
+
 def algorithmic_flops(n_nodes: int, n_edges: int, n_events: int, F0: int = 19, n_pool: int = 4) -> float:
     """Reference-formulation forward GEMM FLOPs, MAC = 2 FLOP."""
     return 2.0 * (n_edges * (2 * F0 * 128 + 128 * 256) + 3 * n_edges * (512 * 336 + 336 * 256)
@@ -190,11 +220,12 @@ def main():
                           + 2 * N * (336 * 256 + (F0 + 1024) * 336) + sum(2 * N * 2 * h1 * f for f, h1, _ in conv[1:]),
             "linear_wgrad": sum(2 * N * f * 2 * h1 for f, h1, _ in conv) + 2 * N * ((F0 + 1024) * 336 + 336 * 256),
         }
-        hbm_bytes = {   # algorithmic bytes per step of the HBM-bound groups (bf16 dpre rows, fp32 activations)
-            "edgeconv_dq_gather": sum(E * 2 * (h1 + 31) // 32 * 32 + N * 4 * h1 for _, h1, _ in conv),
+        act = 2 if args.dtype == "bf16" else 4     # bytes per stored activation element
+        hbm_bytes = {   # algorithmic bytes per step of the HBM-bound groups
+            "edgeconv_dq_gather": sum((E + N) * act * ((h1 + 31) // 32 * 32) for _, h1, _ in conv),
             "knn_graph": 4 * (N * 3 * 4 + N * 9 * 4),
             "colsum": sum(N * 4 * h1 for _, h1, _ in conv) + N * 4 * (336 + 256),
-            "segment_pool_fwd": N * 256 * 4, "segment_pool_bwd": N * 256 * 4 * 2,
+            "segment_pool_fwd": N * 256 * 4, "segment_pool_bwd": N * 256 * (4 + act),
         }
         dom = max(timers.items(), key=lambda kv: kv[1][1]) if timers else ("none", (1, 0.0))
         name, (launches, ms) = dom
@@ -233,6 +264,7 @@ def main():
             "phase_ms_per_step": {k: v[1] / prof_steps for k, v in sorted(timers.items(), key=lambda kv: -kv[1][1])},
             "launch": launch, "host_issue_ms": host_issue_ms,
             "final_loss": float(loss.detach()),
+            "measured_peaks": measured_peaks(dev),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_events, args.cpu_steps)

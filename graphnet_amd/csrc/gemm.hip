@@ -292,7 +292,7 @@ constexpr int TN2_ROWS = 64, TN2_N1 = 256, TN2_K = 128;
 template <typename DYT, typename XT>
 __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
     const DYT* __restrict__ dY, long long lddy, int N1, Segs x, int M, int nparts,
-    float* __restrict__ slab, float* __restrict__ db_part, int Ktot, int n1_tiles, int k_tiles)
+    float* __restrict__ slab, float* __restrict__ db_part, int Ktot, int n1_tiles, int k_tiles, int xcd_group)
 {
     constexpr int YP = tr_pitch_g(TN2_N1 * 2);      // 576
     constexpr int XP = tr_pitch_g(TN2_K * 2);       // 320
@@ -301,10 +301,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    // blockIdx.x -> (part, k tile, n1 tile)
-    const int t1 = (int)blockIdx.x % n1_tiles;
-    int tk = ((int)blockIdx.x / n1_tiles) % k_tiles;
-    const int part = (int)blockIdx.x / (n1_tiles * k_tiles);
+    // blockIdx.x -> (part, k tile, n1 tile).  xcd_group: the populations (n1 tile, k tile) of one row range
+    // are dealt to the SAME XCD (blockIdx round-robins over 8 XCDs), so the dY / X rows they all read come
+    // from HBM once and from that XCD's L2 for the others (measured 2.2x the algorithmic bytes without).
+    const int pops = n1_tiles * k_tiles;
+    int pop, part;
+    if (xcd_group) {
+        const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        pop = slot % pops;
+        part = (slot / pops) * 8 + xcd;
+    } else {
+        pop = (int)blockIdx.x % pops;
+        part = (int)blockIdx.x / pops;
+    }
+    if (part >= nparts) return;
+    const int t1 = pop % n1_tiles;
+    int tk = pop / n1_tiles;
     int kcol0 = 0, kout0 = 0, xw = 0;
     const XT* xp = nullptr;
     long long ldx = 0;
@@ -568,14 +580,21 @@ int gemm_tn_splits_for(int M, int tiles) {
 hipError_t launch_colsum(const float* X, long long ld, int M, int C, float* part, float* out, int accum, hipStream_t st);
 int colsum_blocks(int M);
 int device_cus();
+// populations of one row range share an XCD when that leaves < 1/8 of the CUs idle
+static bool gemm_tn_xcd_group(int pops) {
+    const int per_xcd = device_cus() / 8;
+    return pops > 0 && pops <= per_xcd && (per_xcd / pops) * pops * 8 >= per_xcd * 7;
+}
 // number of row-range parts (= slabs) the weight-gradient kernels write
 int gemm_tn_parts(int mode, int M, int N1, const int* widths, int nseg) {
     if (mode == 1) {
         int kt = 0;
         for (int s = 0; s < nseg; ++s) kt += cdiv_(widths[s], TN2_K);
         const int pops = cdiv_(N1, TN2_N1) * kt;
-        int parts = device_cus() / (pops > 0 ? pops : 1);
         const int maxp = cdiv_(M > 0 ? M : 1, TN2_ROWS);
+        int parts;
+        if (gemm_tn_xcd_group(pops)) parts = 8 * ((device_cus() / 8) / pops);     // whole row ranges per XCD
+        else parts = device_cus() / (pops > 0 ? pops : 1);
         if (parts > maxp) parts = maxp;
         return parts > 0 ? parts : 1;
     }
@@ -602,20 +621,22 @@ hipError_t launch_gemm_tn(int mode, const void* dY, int dy_lowp, long long lddy,
     if (mode == 1) {
         const int parts = gemm_tn_parts(mode, M, N1, x.width, x.nseg);
         const int n1t = cdiv_(N1, TN2_N1);
-        const dim3 grid(n1t * ktiles2 * parts), block(512);
+        const int pops2 = n1t * ktiles2;
+        const int grp = gemm_tn_xcd_group(pops2) && parts % 8 == 0 ? 1 : 0;
+        const dim3 grid(grp ? 8 * (parts / 8) * pops2 : pops2 * parts), block(512);
         float* dbp = db ? db_part : nullptr;
         if (dy_lowp && x_lowp)
             hipLaunchKernelGGL((gemm_tn_v2_kernel<__bf16, __bf16>), grid, block, 0, st, (const __bf16*)dY, lddy, N1, x, M,
-                               parts, slab, dbp, Ktot, n1t, ktiles2);
+                               parts, slab, dbp, Ktot, n1t, ktiles2, grp);
         else if (dy_lowp)
             hipLaunchKernelGGL((gemm_tn_v2_kernel<__bf16, float>), grid, block, 0, st, (const __bf16*)dY, lddy, N1, x, M,
-                               parts, slab, dbp, Ktot, n1t, ktiles2);
+                               parts, slab, dbp, Ktot, n1t, ktiles2, grp);
         else if (x_lowp)
             hipLaunchKernelGGL((gemm_tn_v2_kernel<float, __bf16>), grid, block, 0, st, (const float*)dY, lddy, N1, x, M,
-                               parts, slab, dbp, Ktot, n1t, ktiles2);
+                               parts, slab, dbp, Ktot, n1t, ktiles2, grp);
         else
             hipLaunchKernelGGL((gemm_tn_v2_kernel<float, float>), grid, block, 0, st, (const float*)dY, lddy, N1, x, M,
-                               parts, slab, dbp, Ktot, n1t, ktiles2);
+                               parts, slab, dbp, Ktot, n1t, ktiles2, grp);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(count, RS_ELEMS)), dim3(256), 0, st, slab, parts, count, dW, accum);
         if (db)
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(N1, RS_ELEMS)), dim3(256), 0, st, db_part, parts, (long long)N1,

@@ -8,8 +8,14 @@ shape buckets in real training).  The gradient all-reduce of the data-parallel p
 the captured graphs (graph 1: zero-grad + forward + backward, eager: one flat RCCL all-reduce,
 graph 2: optimizer step), so RCCL is never part of a capture.
 
-Semantics are those of ``StandardModel.fit``'s eager loop (``models/easy_model.py:237-256``);
-``tests/test_gpu_model.py`` checks that graphed and eager steps give bitwise identical weights.
+Semantics are those of ``StandardModel.fit``'s eager loop (``models/easy_model.py:237-256``).
+
+Status: EXPERIMENTAL, off by default (``bench.py --graph``).  At test scale (24 events) the replay follows
+the eager loop to ~1e-6 in the loss (not bit for bit: the library GEMMs of the tiny read-out pick other
+algorithms under capture).  At bench scale (1024 events) a replay raised "Memory access fault ... write
+access to a read-only page"; root cause not found, so nothing in the default path depends on this module.
+At least one eager warm-up step is required: the optimizer creates its state on the first ``step()``, and
+state created *inside* the capture would be re-initialised by every replay.
 """
 from __future__ import annotations
 
@@ -27,7 +33,7 @@ class GraphedTrainStep:
                  sync: Optional[FlatGradAllReduce] = None, scheduler: Any = None, warmup: int = 2):
         self.model, self.opt, self.sched = model, optimizer, scheduler
         self.sync = sync if sync is not None else FlatGradAllReduce(model.parameters())
-        self.warmup = warmup
+        self.warmup = max(1, int(warmup))          # >= 1: optimizer state must exist before the capture
         self._graphs: Dict[Tuple, Tuple] = {}
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         dev = self.sync.flat.device
