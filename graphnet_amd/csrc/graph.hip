@@ -26,6 +26,7 @@ struct KnnCols { int c[KNN_DMAX]; };
 // wave only ever scans candidates of ITS OWN event (a tile spanning events would scan their union).
 // tile_ptr[e] = sum_{e'<e} ceil(n_e'/64) is built once per batch by knn_plan_kernel; a workgroup (one
 // wave) finds its event by binary search over tile_ptr (wave-uniform scalar loads).
+constexpr int KNN_BIG = 1024;  // events above this many pulses: candidates split over 8 waves per query tile
 __global__ __launch_bounds__(256) void knn_plan_kernel(const int* __restrict__ ptr, int B, int* __restrict__ tile_ptr) {
     __shared__ int lds[256 / 64];
     int carry = 0;
@@ -48,23 +49,35 @@ __global__ __launch_bounds__(256) void knn_plan_kernel(const int* __restrict__ p
         if (e < B) tile_ptr[e] = carry + base + incl - v;
         carry += tot;
     }
-    if (threadIdx.x == 0) tile_ptr[B] = carry;
+    if (threadIdx.x == 0) { tile_ptr[B] = carry; tile_ptr[B + 1] = 0; }
+    __syncthreads();
+    // tiles of the events above KNN_BIG pulses (handled by the 8-wave kernel): count at [B+1], ids from [B+2]
+    for (int e = threadIdx.x; e < B; e += 256) {
+        const int n = max(ptr[e + 1] - ptr[e], 0);
+        if (n > KNN_BIG) {
+            const int nt = (n + KNN_TILE - 1) / KNN_TILE;
+            const int pos = atomicAdd(&tile_ptr[B + 1], nt);
+            for (int t = 0; t < nt; ++t) tile_ptr[B + 2 + pos + t] = tile_ptr[e] + t;
+        }
+    }
 }
 
 // DT: number of coordinates at compile time (3 = the usual x,y,z: the distance is 8 instructions), or 0 =
 // run-time D <= 8 (every dimension guarded by a select).
-template <int KMAX, int DT>
-__global__ __launch_bounds__(KNN_TILE) void knn_kernel(
-    const float* __restrict__ x, long long ldx, KnnCols cols, int Drt,
+// CW: waves per query tile.  CW = 1 handles the events with <= KNN_BIG pulses (one wave scans the whole
+// event).  CW = 8 handles the larger ones: the candidate range is cut in 8 contiguous pieces, one per wave,
+// each wave keeps its own sorted list, and wave 0 merges the 8 lists in ascending piece order with the same
+// insertion rule - the result is the same total order (d2, j) as one long scan.  Without it a single
+// 5000-pulse event in a batch is a 0.5 ms tail on a 0.13 ms kernel.
+template <int KMAX, int DT, int CW>
+__device__ __forceinline__ void knn_tile(
+    const int w, unsigned char* lds_raw, const float* __restrict__ x, long long ldx, const KnnCols& cols, int Drt,
     const int* __restrict__ ptr, const int* __restrict__ tile_ptr, int B, int N, int k, int strict,
     int* __restrict__ nbr, int* __restrict__ ovf)
 {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) float cand[KNN_DMAX][KNN_CH];
     constexpr int DM = DT > 0 ? DT : KNN_DMAX;         // dimensions touched by the unrolled loops
     const int D = DT > 0 ? DT : Drt;
-    const int w = blockIdx.x;
-    if (w >= tile_ptr[B]) return;
     int elo = 0, ehi = B;                       // largest e with tile_ptr[e] <= w  (empty events share a value)
     while (ehi - elo > 1) {
         const int mid = (elo + ehi) >> 1;
@@ -72,10 +85,13 @@ __global__ __launch_bounds__(KNN_TILE) void knn_kernel(
     }
     const int ev = elo;
     const int hi = min(ptr[ev + 1], N), lo = min(max(ptr[ev], 0), hi);   // never index past x[N]
+    if ((CW == 1) != (hi - lo <= KNN_BIG)) return;   // the other launch owns this event (workgroup-uniform)
     const int kk = strict ? k : k + 1;
-    const int q = lo + (w - tile_ptr[ev]) * KNN_TILE + (int)threadIdx.x;
+    const int lane = (int)threadIdx.x & (KNN_TILE - 1), wv = (int)threadIdx.x / KNN_TILE;
+    const int q = lo + (w - tile_ptr[ev]) * KNN_TILE + lane;
     const bool active = q < hi;
     const float INF = __builtin_inff();
+    float (*cand)[KNN_CH] = reinterpret_cast<float (*)[KNN_CH]>(lds_raw + wv * DM * KNN_CH * 4);   // this wave's staging
 
     float qc[DM];
 #pragma unroll
@@ -85,11 +101,30 @@ __global__ __launch_bounds__(KNN_TILE) void knn_kernel(
 #pragma unroll
     for (int e = 0; e < KMAX; ++e) { bd[e] = 1e10f; bj[e] = -1; }
 
-    for (int c0 = lo; c0 < hi; c0 += KNN_CH) {
-        const int cn = min(KNN_CH, hi - c0);
+    // sorted insert after equal keys: new[t] = med3(old[t-1], d2, old[t]); the index follows
+#define GN_KNN_INSERT(d2_, j_)                                                                        \
+    if ((d2_) < bd[KMAX - 1]) {                                                                       \
+        bool ct = true;                                   /* d2 < old[t] */                           \
+        _Pragma("unroll") for (int t = KMAX - 1; t > 0; --t) {                                        \
+            const bool cp = (d2_) < bd[t - 1];            /* d2 < old[t-1] */                         \
+            bj[t] = cp ? bj[t - 1] : (ct ? (j_) : bj[t]);                                             \
+            bd[t] = __builtin_amdgcn_fmed3f(bd[t - 1], (d2_), bd[t]);                                 \
+            ct = cp;                                                                                  \
+        }                                                                                             \
+        bj[0] = ct ? (j_) : bj[0];                                                                    \
+        bd[0] = ct ? (d2_) : bd[0];                                                                   \
+    }
+
+    // this wave's piece of the candidate range (multiple of 4 long except the last)
+    const int piece = CW == 1 ? hi - lo : (((hi - lo + CW - 1) / CW + 3) & ~3);
+    const int plo = min(lo + wv * piece, hi), phi = min(plo + piece, hi);
+    const int nchunk = (piece + KNN_CH - 1) / KNN_CH;        // same trip count for every wave (barriers inside)
+    for (int ci = 0; ci < nchunk; ++ci) {
+        const int c0 = plo + ci * KNN_CH;
+        const int cn = max(0, min(KNN_CH, phi - c0));
         const int cn4 = (cn + 3) & ~3;
         __syncthreads();
-        for (int t = threadIdx.x; t < cn4; t += KNN_TILE) {
+        for (int t = lane; t < cn4; t += KNN_TILE) {
             const float* row = x + (long long)(c0 + min(t, cn - 1)) * ldx;
 #pragma unroll
             for (int d = 0; d < DM; ++d)
@@ -120,23 +155,34 @@ __global__ __launch_bounds__(KNN_TILE) void knn_kernel(
                 // inactive lanes, the query itself (strict) and NaN/inf distances never enter the list
                 const bool ok = active && !(strict && j == q) && d2 < INF;
                 d2 = ok ? d2 : INF;
-                if (d2 < bd[KMAX - 1]) {
-                    // sorted insert after equal keys: new[t] = med3(old[t-1], d2, old[t]); index follows
-                    bool ct = true;                                   // d2 < old[t]
-#pragma unroll
-                    for (int t = KMAX - 1; t > 0; --t) {
-                        const bool cp = d2 < bd[t - 1];               // d2 < old[t-1]
-                        bj[t] = cp ? bj[t - 1] : (ct ? j : bj[t]);
-                        bd[t] = __builtin_amdgcn_fmed3f(bd[t - 1], d2, bd[t]);
-                        ct = cp;
-                    }
-                    bj[0] = ct ? j : bj[0];
-                    bd[0] = ct ? d2 : bd[0];
-                }
+                GN_KNN_INSERT(d2, j);
             }
         }
     }
-    if (active) {
+    if constexpr (CW > 1) {
+        // merge: waves 1.. publish their lists, wave 0 inserts them in ascending piece (= index) order
+        __syncthreads();                                    // everybody is done with the staging area
+        float* ld = reinterpret_cast<float*>(lds_raw);
+        int* lj = reinterpret_cast<int*>(lds_raw) + (CW - 1) * KMAX * KNN_TILE;
+        if (wv > 0) {
+#pragma unroll
+            for (int e = 0; e < KMAX; ++e) {
+                ld[((wv - 1) * KMAX + e) * KNN_TILE + lane] = bd[e];
+                lj[((wv - 1) * KMAX + e) * KNN_TILE + lane] = bj[e];
+            }
+        }
+        __syncthreads();
+        if (wv == 0)
+        for (int c = 0; c < CW - 1; ++c)
+            for (int e = 0; e < KMAX; ++e) {
+                const float d2 = ld[(c * KMAX + e) * KNN_TILE + lane];
+                const int j = lj[(c * KMAX + e) * KNN_TILE + lane];
+                if (__ballot(d2 < bd[KMAX - 1]) == 0ull) break;          // sorted: nothing further in this list
+                GN_KNN_INSERT(d2, j);
+            }
+    }
+#undef GN_KNN_INSERT
+    if (active && wv == 0) {
         int c = 0;
         int extra = -1;
 #pragma unroll
@@ -152,6 +198,29 @@ __global__ __launch_bounds__(KNN_TILE) void knn_kernel(
         }
         for (; c < k; ++c) nbr[(long long)q * k + c] = -1;
         if (ovf) ovf[q] = extra;
+    }
+}
+
+template <int KMAX, int DT, int CW>
+__global__ __launch_bounds__(KNN_TILE * CW) void knn_kernel(
+    const float* __restrict__ x, long long ldx, KnnCols cols, int Drt,
+    const int* __restrict__ ptr, const int* __restrict__ tile_ptr, int B, int N, int k, int strict,
+    int* __restrict__ nbr, int* __restrict__ ovf)
+{
+    constexpr int DM = DT > 0 ? DT : KNN_DMAX;
+    constexpr int CAND_BYTES = CW * DM * KNN_CH * 4;
+    constexpr int LIST_BYTES = (CW - 1) * KMAX * KNN_TILE * 8;
+    constexpr int LDS_BYTES = CAND_BYTES > LIST_BYTES ? CAND_BYTES : LIST_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    if constexpr (CW == 1) {
+        if ((int)blockIdx.x < tile_ptr[B])
+            knn_tile<KMAX, DT, CW>((int)blockIdx.x, lds_raw, x, ldx, cols, Drt, ptr, tile_ptr, B, N, k, strict, nbr, ovf);
+    } else {
+        const int nbig = tile_ptr[B + 1];                   // usually 0: the workgroups leave at once
+        for (int i = blockIdx.x; i < nbig; i += gridDim.x) {
+            knn_tile<KMAX, DT, CW>(tile_ptr[B + 2 + i], lds_raw, x, ldx, cols, Drt, ptr, tile_ptr, B, N, k, strict, nbr, ovf);
+            __syncthreads();                                 // LDS reuse by the next tile
+        }
     }
 }
 
@@ -445,13 +514,22 @@ hipError_t launch_knn(const float* x, long long ldx, const int* cols, int D, con
     dim3 grid((unsigned)tiles), block(KNN_TILE);
 #define GN_KNN_LAUNCH(KM)                                                                                       \
     {                                                                                                           \
-        if (D == 3)                                                                                             \
-            hipLaunchKernelGGL((knn_kernel<KM, 3>), grid, block, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, k,  \
+        const dim3 blockb(KNN_TILE * 8), gridb(1024);        /* second launch: events above KNN_BIG pulses */   \
+        if (D == 3) {                                                                                           \
+            hipLaunchKernelGGL((knn_kernel<KM, 3, 1>), grid, block, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, k, \
                                strict, nbr, ovf);                                                               \
-        else                                                                                                    \
-            hipLaunchKernelGGL((knn_kernel<KM, 0>), grid, block, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, k,  \
+            if (bigpossible)                                                                                    \
+                hipLaunchKernelGGL((knn_kernel<KM, 3, 8>), gridb, blockb, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, \
+                                   k, strict, nbr, ovf);                                                        \
+        } else {                                                                                                \
+            hipLaunchKernelGGL((knn_kernel<KM, 0, 1>), grid, block, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, k, \
                                strict, nbr, ovf);                                                               \
+            if (bigpossible)                                                                                    \
+                hipLaunchKernelGGL((knn_kernel<KM, 0, 8>), gridb, blockb, 0, st, x, ldx, kc, D, ptr, tile_ptr, B, N, \
+                                   k, strict, nbr, ovf);                                                        \
+        }                                                                                                       \
     }
+    const bool bigpossible = N > KNN_BIG;                   // an event can only be that large if the batch is
     if (kk <= 9) GN_KNN_LAUNCH(9)
     else if (kk <= 17) GN_KNN_LAUNCH(17)
     else GN_KNN_LAUNCH(33)

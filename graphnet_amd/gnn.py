@@ -159,7 +159,7 @@ class _DynEdgeFunction(torch.autograd.Function):
             if l + 1 < nconv:
                 cols = _subset_cols(cfg["features_subset"], H2)
                 if plan is None:
-                    plan = ops.knn_plan(ptr)                  # query-tile plan: once per batch, all layers
+                    plan = ops.knn_plan(ptr, N)               # query-tile plan: once per batch, all layers
                 if lowp and len(cols) <= 8:
                     # bf16 activations: the k-NN coordinates leave the kernel as a separate fp32 copy
                     out, mask, coords = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2.contiguous(), H2, coord_cols=cols)

@@ -46,8 +46,10 @@ int gn_abi_version(void);
 int gn_knn_graph(const float* x, int64_t ldx, const int32_t* cols_host, int32_t D,
                  const int32_t* ptr, const int32_t* tile_ptr, int32_t B, int32_t N, int32_t k, int32_t strict,
                  int32_t* nbr, int32_t* ovf, void* stream);
-/* Query-tile plan of a batch (once per batch, shared by every k-NN layer): tile_ptr[e] = number of
- * 64-query tiles of the events before e, tile_ptr[B] = their total (<= N/64 + B).  Device int32[B+1]. */
+/* Query-tile plan of a batch (once per batch, shared by every k-NN layer).  Device int32[2B + 2 + N/64]:
+ * tile_ptr[e] = number of 64-query tiles of the events before e, tile_ptr[B] = their total (<= N/64 + B),
+ * tile_ptr[B+1] = number of tiles that belong to events above 1024 pulses, their ids from tile_ptr[B+2]
+ * (those tiles are scanned by 8 waves each, the others by one). */
 int gn_knn_plan(const int32_t* ptr, int32_t B, int32_t* tile_ptr, void* stream);
 
 /* exclusive scan; tmp: >= gn_scan_tmp_ints(n) ints; total (optional) receives the sum */

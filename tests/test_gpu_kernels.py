@@ -86,9 +86,11 @@ def test_knn_edge_cases(oracle):
     from graphnet_amd import ops
     # ragged: events of 1, 2, 3 nodes (degree n-1), > k duplicates, D = 4 columns, big event
     rng = np.random.default_rng(5)
-    sizes = [1, 2, 3, 30, 1500, 9, 2]
+    sizes = [1, 2, 3, 30, 1500, 9, 2, 2300]            # > 1024 pulses: candidates split over 8 waves per tile
     x = rng.normal(size=(sum(sizes), 6)).astype(np.float32)
     x[40:60, :4] = x[39, :4]
+    x[216:236, :4] = x[39, :4]                          # the same point again, in another wave's piece (ties)
+    x[1600:1640, :4] = x[3000, :4]
     ptr = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64)
     n = ptr[1:] - ptr[:-1]
     batch32 = torch.repeat_interleave(torch.arange(len(n)), n).to(torch.int32).to(DEV)
@@ -96,6 +98,9 @@ def test_knn_edge_cases(oracle):
     for cols in ([0, 1, 2], [0, 1, 2, 3], [5, 1]):
         t = ops.knn_graph(xt.to(DEV), cols, batch32, ptr.to(torch.int32).to(DEV), 8)
         _cmp_table(t, _oracle_table(oracle, xt, ptr, 8, cols, "compat"), 8)
+    for kk, mode in ((16, "strict"), (3, "compat")):
+        t = ops.knn_graph(xt.to(DEV), [0, 1, 2], batch32, ptr.to(torch.int32).to(DEV), kk, strict=(mode == "strict"))
+        _cmp_table(t, _oracle_table(oracle, xt, ptr, kk, [0, 1, 2], mode), kk)
     # strided view (latent features are a column slice of a wider row)
     wide = torch.zeros(x.shape[0], 64)
     wide[:, 10:16] = xt
