@@ -12,8 +12,9 @@ Semantics are those of ``StandardModel.fit``'s eager loop (``models/easy_model.p
 
 Status: EXPERIMENTAL, off by default (``bench.py --graph``).  At test scale (24 events) the replay follows
 the eager loop to ~1e-6 in the loss (not bit for bit: the library GEMMs of the tiny read-out pick other
-algorithms under capture).  At bench scale (1024 events) a replay raised "Memory access fault ... write
-access to a read-only page"; root cause not found, so nothing in the default path depends on this module.
+algorithms under capture).  At bench scale (1024 events) twenty replays enqueued back to back raised "Memory access fault ... write access to
+a read-only page" (ten did not; synchronised replays never did), hence the in-flight limit below; nothing in
+the default path depends on this module.
 At least one eager warm-up step is required: the optimizer creates its state on the first ``step()``, and
 state created *inside* the capture would be re-initialised by every replay.
 """
@@ -29,12 +30,15 @@ from .parallel import FlatGradAllReduce
 
 
 class GraphedTrainStep:
+    MAX_IN_FLIGHT = 2
+
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer,
                  sync: Optional[FlatGradAllReduce] = None, scheduler: Any = None, warmup: int = 2):
         self.model, self.opt, self.sched = model, optimizer, scheduler
         self.sync = sync if sync is not None else FlatGradAllReduce(model.parameters())
         self.warmup = max(1, int(warmup))          # >= 1: optimizer state must exist before the capture
         self._graphs: Dict[Tuple, Tuple] = {}
+        self._events: list = []
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         dev = self.sync.flat.device
         self._lr = []
@@ -90,10 +94,18 @@ class GraphedTrainStep:
             for k, v in batch.items():
                 if isinstance(v, torch.Tensor):
                     static[k].copy_(v, non_blocking=True)
+        # At most MAX_IN_FLIGHT replays are queued: twenty replays (~5000 kernel nodes) enqueued back to back
+        # faulted the GPU ("write access to a read-only page") while ten did not, so the runtime seems to run
+        # out of some per-launch resource; waiting for the replay before the previous one costs nothing.
+        if len(self._events) >= self.MAX_IN_FLIGHT:
+            self._events.pop(0).synchronize()
         g1.replay()
         if g2 is not None:
             self.sync.all_reduce()
             g2.replay()
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events.append(ev)
         if self.sched is not None:
             self.sched.step()                               # assigns python floats ...
             for group, t in zip(self.opt.param_groups, self._lr):

@@ -26,7 +26,17 @@ m2, o2, s2 = make()
 W = 2                                      # eager warm-up steps inside the first call (real optimizer steps:
                                            # they also create the Adam state BEFORE the capture)
 step = GraphedTrainStep(m2, o2, s2, warmup=W)
-l2 = [float(step(b)) for _ in range(steps - W)]
+if len(sys.argv) > 3 and sys.argv[3] == "nosync":      # replays enqueued back to back, no host sync in between
+    lt = [step(b).detach().clone() for _ in range(steps - W)]
+    torch.cuda.synchronize()
+    l2 = [float(t) for t in lt]
+else:
+    l2 = [float(step(b)) for _ in range(steps - W)]
 torch.cuda.synchronize()
 print("eager  ", l1[W:]); print("graphed", l2)
+if len(sys.argv) > 3 and sys.argv[3] == "eager_after":
+    for _ in range(2):                     # eager steps on the graphed model after the capture (what bench.py does)
+        s2.zero_grad(); loss = m2.shared_step(b); loss.backward(); s2(); o2.step()
+    torch.cuda.synchronize()
+    print("eager steps after the graph: ok", float(loss))
 print("weights equal:", all(torch.equal(p, q) for p, q in zip(m1.parameters(), m2.parameters())))
