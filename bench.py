@@ -178,6 +178,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed ramp-up before the W warm-up steps: the first ~0.3 s of sustained load run at ~25 % lower
+    # throughput (GPU clock / power-state ramp and allocator growth: 10.0 ms/step with 5 warm-up steps vs
+    # 7.5 ms/step with 40), so a short warm-up would time the ramp instead of the steady state.
+    t_ramp = time.perf_counter()
+    n_ramp = 0
+    while n_ramp < 30 or time.perf_counter() - t_ramp < 0.75:
+        step()
+        n_ramp += 1
+        if n_ramp % 10 == 0:
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()

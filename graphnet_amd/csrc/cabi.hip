@@ -181,6 +181,11 @@ int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int
     return fail(r, "gn_edgeconv_dq_gather");
 }
 
+int gn_pack_weights(const int64_t* desc, int32_t ndesc, void* stream) {
+    if (ndesc < 0 || (ndesc > 0 && !desc)) return bad("gn_pack_weights", "descriptor table");
+    return fail(gn::launch_pack_weights(reinterpret_cast<const long long*>(desc), ndesc, S(stream)), "gn_pack_weights");
+}
+
 int gn_segment_pool_fwd(const float* x, int64_t ldx, int32_t C, const int32_t* ptr, int32_t B, const int32_t* codes_host,
                         int32_t ns, float* out, int32_t* argmin, int32_t* argmax, void* stream) {
     hipError_t r = gn::launch_pool_fwd(x, ldx, C, ptr, B, codes_host, ns, out, argmin, argmax, S(stream));

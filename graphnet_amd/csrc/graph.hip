@@ -251,13 +251,19 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* lds)
     return base + incl - v;
 }
 
+// FLAG: scan the predicate (in[i] >= 0) instead of in[i] (stream compaction without a separate flag pass)
+template <bool FLAG>
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_phase1(const int* __restrict__ in, int n,
                                                           int* __restrict__ out, int* __restrict__ bsum) {
     __shared__ int lds[SCAN_BLOCK / 64];
     const int base = (blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
     int v[SCAN_ITEMS], s = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = (base + i < n) ? in[base + i] : 0; s += v[i]; }
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int x = (base + i < n) ? in[base + i] : (FLAG ? -1 : 0);
+        v[i] = FLAG ? (x >= 0 ? 1 : 0) : x;
+        s += v[i];
+    }
     int tot;
     int ex = block_exclusive_scan(s, &tot, lds);
 #pragma unroll
@@ -284,6 +290,24 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_phase3(int* __restrict__ out,
     const int add = bsum[blockIdx.x];
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) out[base + i] += add;
+}
+// phases 2 + 3 in one launch (few blocks): every block sums the RAW block totals before it by itself
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_phase23(int* __restrict__ out, int n, const int* __restrict__ bsum,
+                                                           int* __restrict__ total_out) {
+    __shared__ int lds[SCAN_BLOCK / 64];
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_BLOCK) part += bsum[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = part;
+    __syncthreads();
+    int add = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_BLOCK / 64; ++i) add += lds[i];
+    const int base = (blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) out[base + i] += add;
+    if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = add + bsum[blockIdx.x];
 }
 
 // ---------------------------------------------------------------- overflow compaction
@@ -316,7 +340,7 @@ __global__ __launch_bounds__(256) void rev_count(const int* __restrict__ nbr, in
 __global__ __launch_bounds__(256) void rev_fill(const int* __restrict__ nbr, int N, int K, int S,
                                                 const int* __restrict__ ovf_src, const int* __restrict__ ovf_cnt,
                                                 const int* __restrict__ rev_ptr, int* __restrict__ cursor,
-                                                int* __restrict__ rev_rows) {
+                                                int* __restrict__ rev_rows, int* __restrict__ hub_count) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long main_rows = (long long)N * S;
     int j = -1;
@@ -327,9 +351,10 @@ __global__ __launch_bounds__(256) void rev_fill(const int* __restrict__ nbr, int
         j = ovf_src[t - main_rows];
     }
     if (j >= 0) {
-        const int p = atomicAdd(&cursor[j], 1);
+        const int p = atomicSub(&cursor[j], 1) - 1;      // cursor[j] = in-degree left to place: counts down to 0
         rev_rows[rev_ptr[j] + p] = (int)t;
     }
+    if (t == 0) *hub_count = 0;                          // reset for rev_find_hubs (next kernel)
 }
 
 // The in-edge lists are filled with atomics (arbitrary order).  The dQ gather sums rows in ascending row
@@ -538,20 +563,28 @@ hipError_t launch_knn(const float* x, long long ldx, const int* cols, int D, con
 }
 
 // out[i] = sum_{t<i} in[i]; total (optional) = sum of all.  tmp: >= cdiv(n, 2048) ints.
-hipError_t launch_scan(const int* in, int* out, int n, int* tmp, int* total, hipStream_t st) {
+// exclusive scan of in[] (flag = false) or of the predicate in[i] >= 0 (flag = true)
+static hipError_t launch_scan_impl(const int* in, int* out, int n, int* tmp, int* total, bool flag, hipStream_t st) {
     const int per = SCAN_BLOCK * SCAN_ITEMS;
     const int nb = cdiv(n > 0 ? n : 1, per);
-    hipLaunchKernelGGL(scan_phase1, dim3(nb), dim3(SCAN_BLOCK), 0, st, in, n, out, tmp);
-    hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(SCAN_BLOCK), 0, st, tmp, nb, total);
-    hipLaunchKernelGGL(scan_phase3, dim3(nb), dim3(SCAN_BLOCK), 0, st, out, n, tmp);
+    if (flag) hipLaunchKernelGGL(scan_phase1<true>, dim3(nb), dim3(SCAN_BLOCK), 0, st, in, n, out, tmp);
+    else hipLaunchKernelGGL(scan_phase1<false>, dim3(nb), dim3(SCAN_BLOCK), 0, st, in, n, out, tmp);
+    if (nb <= 1024) {                                  // two launches: each block adds up the block totals before it
+        hipLaunchKernelGGL(scan_phase23, dim3(nb), dim3(SCAN_BLOCK), 0, st, out, n, tmp, total);
+    } else {
+        hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(SCAN_BLOCK), 0, st, tmp, nb, total);
+        hipLaunchKernelGGL(scan_phase3, dim3(nb), dim3(SCAN_BLOCK), 0, st, out, n, tmp);
+    }
     return hipGetLastError();
+}
+hipError_t launch_scan(const int* in, int* out, int n, int* tmp, int* total, hipStream_t st) {
+    return launch_scan_impl(in, out, n, tmp, total, false, st);
 }
 
 hipError_t launch_ovf_compact(const int* ovf, int N, int* flag_pos /*[N]*/, int* tmp, int* ovf_centre, int* ovf_src,
                               int* ovf_cnt, hipStream_t st) {
     if (N == 0) return hipMemsetAsync(ovf_cnt, 0, sizeof(int), st);
-    hipLaunchKernelGGL(flag_nonneg, dim3(cdiv(N, 256)), dim3(256), 0, st, ovf, N, flag_pos);
-    hipError_t e = launch_scan(flag_pos, flag_pos, N, tmp, ovf_cnt, st);
+    hipError_t e = launch_scan_impl(ovf, flag_pos, N, tmp, ovf_cnt, true, st);      // positions of the entries >= 0
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ovf_write, dim3(cdiv(N, 256)), dim3(256), 0, st, ovf, flag_pos, N, ovf_centre, ovf_src);
     return hipGetLastError();
@@ -566,12 +599,10 @@ hipError_t launch_rev_build(const int* nbr, int N, int K, int S, const int* ovf_
     hipLaunchKernelGGL(rev_count, dim3(cdiv(rows, 256)), dim3(256), 0, st, nbr, N, K, S, ovf_src, ovf_cnt, cursor);
     e = launch_scan(cursor, rev_ptr, N, tmp, rev_ptr + N, st);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)N, st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rev_fill, dim3(cdiv(rows, 256)), dim3(256), 0, st, nbr, N, K, S, ovf_src, ovf_cnt, rev_ptr, cursor, rev_rows);
-    // hub nodes (in-degree > 64): sort their lists once; `cursor` (free now) holds the hub list, tmp[0] its length
-    e = hipMemsetAsync(tmp, 0, sizeof(int), st);
-    if (e != hipSuccess) return e;
+    // cursor still holds the in-degrees (the scan is out of place): rev_fill counts them down to zero
+    hipLaunchKernelGGL(rev_fill, dim3(cdiv(rows, 256)), dim3(256), 0, st, nbr, N, K, S, ovf_src, ovf_cnt, rev_ptr, cursor,
+                       rev_rows, tmp);
+    // hub nodes (in-degree > 64): sort their lists once; `cursor` (all zero now) receives the hub list, tmp[0] its length
     hipLaunchKernelGGL(rev_find_hubs, dim3(cdiv(N, 256)), dim3(256), 0, st, rev_ptr, N, cursor, tmp);
     hipLaunchKernelGGL(rev_sort_kernel, dim3(N < 1024 ? N : 1024), dim3(256), 0, st, rev_ptr, cursor, tmp, rev_rows);
     return hipGetLastError();

@@ -46,6 +46,7 @@ hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p
 hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows, int N,
                             void* dQ, long long ldq, hipStream_t st);
 // pool.hip
+hipError_t launch_pack_weights(const long long* desc, int ndesc, hipStream_t st);
 hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr, int B, const int* codes, int ns,
                            float* out, int* argmin, int* argmax, hipStream_t st);
 hipError_t launch_pool_bwd(const float* gout, int C, const int* ptr, const int* batch, int N, const int* codes, int ns,

@@ -137,6 +137,36 @@ __global__ __launch_bounds__(256) void segment_pool_bwd8_kernel(
     store4<OutT>(dst + 4, v[4], v[5], v[6], v[7]);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight packing: ONE launch per step rewrites every padded / transposed / bf16 operand copy of the weights.
+// A descriptor (10 x int64, built once on the host - parameter storage does not move under in-place
+// optimizers) says: dst[r*d_pitch + c] = src[r*s_row + c*s_col] - (src2 ? src2[r*s_row + c*s_col] : 0)
+// for r < rows, c < cols; dst is bf16 (flag) or fp32.  Pad rows / columns of dst are never touched (zero).
+constexpr int PACK_FIELDS = 10;   // src, src2, dst, s_row, s_col, d_pitch, rows, cols, dst_bf16, reserved
+__global__ __launch_bounds__(256) void pack_weights_kernel(const long long* __restrict__ desc) {
+    const long long* d = desc + (long long)blockIdx.y * PACK_FIELDS;
+    const float* src = reinterpret_cast<const float*>(d[0]);
+    const float* src2 = reinterpret_cast<const float*>(d[1]);
+    const long long s_row = d[3], s_col = d[4], d_pitch = d[5];
+    const long long rows = d[6], cols = d[7], total = rows * cols;
+    const bool lowp = d[8] != 0;
+    // walk the DESTINATION in row-major order unless the source is contiguous along rows (a transpose):
+    // then consecutive threads take consecutive source elements and the (strided) writes are the scattered side
+    const bool by_src = s_row == 1 && s_col != 1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = by_src ? i % rows : i / cols, c = by_src ? i / rows : i % cols;
+        float v = src[r * s_row + c * s_col];
+        if (src2) v -= src2[r * s_row + c * s_col];
+        if (lowp) reinterpret_cast<__bf16*>(d[2])[r * d_pitch + c] = (__bf16)v;
+        else reinterpret_cast<float*>(d[2])[r * d_pitch + c] = v;
+    }
+}
+hipError_t launch_pack_weights(const long long* desc, int ndesc, hipStream_t st) {
+    if (ndesc <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(64, ndesc), dim3(256), 0, st, desc);
+    return hipGetLastError();
+}
+
 hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr, int B, const int* codes, int ns,
                            float* out, int* argmin, int* argmax, hipStream_t st) {
     if (B == 0) return hipSuccess;

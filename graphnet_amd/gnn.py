@@ -85,23 +85,64 @@ def _unpad_cols(dW: Tensor, widths: Sequence[int], unit: int = 4) -> Tensor:
 
 
 class _WeightBuffers:
-    """Persistent, zero-initialised buffers the packed (padded / transposed / bf16) copies of the weights
-    are written into each step.  Only the real block of a buffer is ever written, so the pad rows and
-    columns stay zero: packing a weight is one strided copy-with-cast instead of pad + cat + cast."""
+    """Persistent, zero-initialised buffers holding the packed (padded / transposed / bf16) operand copies of
+    the weights.  Only the real block of a buffer is ever written, so pad rows and columns stay zero.
+
+    The first forward (backward) performs its copies one by one and *records* them as descriptors; as long as
+    the parameter storages do not move (in-place optimizers), every later forward (backward) replays the whole
+    list with ONE ``gn_pack_weights`` launch instead of ~20 small copy kernels."""
 
     def __init__(self) -> None:
         self._b: dict = {}
+        self._tab: dict = {}          # phase -> dict(sig=..., desc=Tensor | None, rec=[...], live=bool)
 
     def get(self, key, shape, dtype, device) -> Tensor:
         t = self._b.get(key)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device:
+            if t is not None:         # a REPLACED buffer leaves dangling pointers in the recorded lists
+                for tab in self._tab.values():
+                    tab["desc"], tab["rec"], tab["live"] = None, None, False
             t = torch.zeros(shape, dtype=dtype, device=device)
             self._b[key] = t
         return t
 
+    def begin(self, phase: str, sig: tuple) -> None:
+        """``sig``: whatever the copy list depends on (mode, parameter storage pointers)."""
+        t = self._tab.get(phase)
+        if t is not None and t["desc"] is not None and t["sig"] == sig:
+            ops.pack_weights(t["desc"])
+            t["live"] = True
+        else:
+            self._tab[phase] = {"sig": sig, "desc": None, "rec": [], "live": False}
+        self._phase = phase
+
+    def copy(self, dst: Tensor, src: Tensor, src2: Optional[Tensor] = None) -> None:
+        """dst[...] = src (- src2): done by the step's pack launch when live, else now (and recorded)."""
+        t = self._tab[self._phase]
+        if t["live"]:
+            return                    # this step's pack launch already wrote it
+        if src2 is None:
+            dst.copy_(src)
+        else:
+            torch.sub(src, src2, out=dst)
+        d2, s2 = (dst, src) if dst.dim() == 2 else (dst.unsqueeze(0), src.unsqueeze(0))
+        if d2.stride(1) != 1 or (src2 is not None and src2.stride() != src.stride()):
+            t["rec"] = None           # not expressible as a descriptor: stay on the copy-by-copy path
+            return
+        if t["rec"] is not None:
+            t["rec"].append([s2.data_ptr(), 0 if src2 is None else src2.data_ptr(), d2.data_ptr(), s2.stride(0),
+                             s2.stride(1), d2.stride(0), d2.shape[0], d2.shape[1], int(dst.dtype == torch.bfloat16), 0])
+
+    def end(self, phase: str, device) -> None:
+        t = self._tab.get(phase)
+        if t is not None and not t["live"] and t["rec"]:
+            t["desc"] = torch.tensor(t["rec"], dtype=torch.int64, device=device)
+        if t is not None:
+            t["live"] = False
+
 
 def _packed(wb: _WeightBuffers, key, W: Tensor, dtype: torch.dtype, kunit: int = 32, koffs=None, widths=None) -> Tensor:
-    """``ops.pack_weight`` layout (``[ceil128(N)][sum ceil_kunit(width)]``) written into a persistent buffer.
+    """``ops.pack_weight`` layout (``[ceil128(N)][sum ceil_kunit(width)]``) kept in a persistent buffer.
     ``widths``: column segments of W, each padded to ``kunit`` in the packed K axis."""
     N, K = int(W.shape[0]), int(W.shape[1])
     widths = [K] if widths is None else list(widths)
@@ -109,7 +150,7 @@ def _packed(wb: _WeightBuffers, key, W: Tensor, dtype: torch.dtype, kunit: int =
     buf = wb.get(key, (ops.round_up(N, 128), kp), dtype, W.device)
     off = offp = 0
     for w in widths:
-        buf[:N, offp: offp + w].copy_(W[:, off: off + w])
+        wb.copy(buf[:N, offp: offp + w], W[:, off: off + w])
         off += w
         offp += ops.round_up(w, kunit)
     return buf
@@ -140,6 +181,8 @@ class _DynEdgeFunction(torch.autograd.Function):
         x0 = ops.concat_globals(x, gv if G else None, batch, ops.round_up(F0, 32), dtype=act)
         xs: List[Tuple[Tensor, int]] = [(x0, F0)]
         wb: _WeightBuffers = cfg["wbuf"]
+        wsig = (mode,) + tuple(p.data_ptr() for p in params)
+        wb.begin("fwd", wsig)
         graphs, PQs, masks = [], [], []
         knn_coords: List[Tensor] = []          # fp32 coordinates each re-built graph was computed from
         plan = None
@@ -150,10 +193,10 @@ class _DynEdgeFunction(torch.autograd.Function):
             Wa, Wb = W1[:, :Fin], W1[:, Fin:]
             # packed [P ; Q] weight: rows 0..H1 = Wa - Wb, rows H1p..H1p+H1 = Wb (pads stay zero)
             Wpq = wb.get(("Wpq", l), (ops.round_up(2 * H1p, 128), ops.round_up(Fin, ku)), dt, x.device)
-            torch.sub(Wa, Wb, out=Wpq[:H1, :Fin])
-            Wpq[H1p:H1p + H1, :Fin].copy_(Wb)
             bpq = wb.get(("bpq", l), (2 * H1p,), torch.float32, x.device)
-            bpq[:H1].copy_(b1)
+            wb.copy(Wpq[:H1, :Fin], Wa, Wb)
+            wb.copy(Wpq[H1p:H1p + H1, :Fin], Wb)
+            wb.copy(bpq[:H1], b1)
             PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), Wpq, 2 * H1p, bias=bpq, out_lowp=lowp)
             W2p = _packed(wb, ("W2p", l), W2, dt)
             if l + 1 < nconv:
@@ -187,6 +230,7 @@ class _DynEdgeFunction(torch.autograd.Function):
                                out_cols=ops.round_up(int(W.shape[0]), 8))
             ys.append((y, int(W.shape[0])))
             segs = [ys[-1]]
+        wb.end("fwd", x.device)
         y_last, P = ys[-1]
         ctx.cfg, ctx.xs, ctx.graphs, ctx.PQs, ctx.masks, ctx.ys = cfg, xs, graphs, PQs, masks, ys
         ctx.params = params
@@ -213,6 +257,7 @@ class _DynEdgeFunction(torch.autograd.Function):
         post_p = [params[4 * nconv + 2 * t: 4 * nconv + 2 * t + 2] for t in range(npost)]
         xs, ys = ctx.xs, ctx.ys
         wb: _WeightBuffers = cfg["wbuf"]
+        wb.begin("bwd", (mode,) + tuple(p.data_ptr() for p in params))
         N = int(xs[0][0].shape[0])
         dev = xs[0][0].device
         grads: List[Optional[Tensor]] = [None] * len(params)
@@ -249,7 +294,7 @@ class _DynEdgeFunction(torch.autograd.Function):
                 for s_ in range(1, len(xs)):
                     w = xs[s_][1]
                     r0 = seg_off[s_] - seg_off[1]
-                    WT[r0: r0 + w, :Pt].copy_(W[:, off: off + w].t())
+                    wb.copy(WT[r0: r0 + w, :Pt], W[:, off: off + w].t())
                     off += w
                 dXcat = torch.empty((N, sum(seg_pad)), dtype=act, device=dev)
                 ops.linear_fwd(mode, _ksegs([(dZ, Pt)]), WT, ncols, out=dXcat[:, seg_off[1]:])
@@ -281,11 +326,12 @@ class _DynEdgeFunction(torch.autograd.Function):
                 # accumulate into the skip-cat gradient of the producing layer
                 WpT = wb.get(("WpT", l), (ops.round_up(Fin, 128), ops.round_up(H1p, ku)), dt, dev)
                 WqT = wb.get(("WqT", l), (ops.round_up(Fin, 128), ops.round_up(H1p, ku)), dt, dev)
-                torch.sub(Wa.t(), Wb.t(), out=WpT[:Fin, :H1])
-                WqT[:Fin, :H1].copy_(Wb.t())
+                wb.copy(WpT[:Fin, :H1], Wa.t(), Wb.t())
+                wb.copy(WqT[:Fin, :H1], Wb.t())
                 d_in = dXcat[:, seg_off[l]: seg_off[l] + Fin]
                 ops.linear_fwd(mode, [(dPQ[:, :H1p], H1p)], WpT, Fin, out=d_in, accum=True)
                 ops.linear_fwd(mode, [(dPQ[:, H1p:], H1p)], WqT, Fin, out=d_in, accum=True)
+        wb.end("bwd", dev)
         return (None, None) + tuple(grads)
 
 

@@ -281,6 +281,12 @@ def pack_weight(W: Tensor, seg_widths: Sequence[int], dtype: torch.dtype, kunit:
     return Wp.to(dtype).contiguous()
 
 
+def pack_weights(desc: Tensor) -> None:
+    """Replay a recorded list of weight-operand copies (``gn_pack_weights``; ``desc`` int64 ``[n, 10]``)."""
+    _need(desc, torch.int64, "desc")
+    _lib.check(_lib.lib().gn_pack_weights(_p(desc), int(desc.shape[0]), _st()))
+
+
 def linear_fwd(mode: int, segs: Sequence[Seg], Wp: Tensor, n_real: int, bias: Optional[Tensor] = None,
                relu: bool = False, gate: Optional[Tensor] = None, out: Optional[Tensor] = None,
                accum: bool = False, out_lowp: bool = False, out_cols: Optional[int] = None) -> Tensor:

@@ -144,6 +144,13 @@ int gn_edgeconv_bwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre,
 int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int32_t* rev_ptr,
                           const int32_t* rev_rows, int32_t N, void* dQ, int64_t ldq, void* stream);
 
+/* ---- operand copies of the weights ------------------------------------------------------- */
+/* One launch rewrites every padded / transposed / bf16 copy of the weights the kernels above consume
+ * (what torch.nn.Linear does implicitly with its own weight).  desc: DEVICE int64[ndesc][10] =
+ * {src, src2 (or 0), dst, s_row, s_col, d_pitch, rows, cols, dst_is_bf16, 0}:
+ * dst[r*d_pitch + c] = src[r*s_row + c*s_col] - (src2 ? src2[r*s_row + c*s_col] : 0), strides in elements. */
+int gn_pack_weights(const int64_t* desc, int32_t ndesc, void* stream);
+
 /* ---- pooling (torch_scatter.scatter_{min,max,sum,mean}, dynedge.py:251-264) ------------ */
 /* codes: HOST int[ns], 0 = min, 1 = max, 2 = sum, 3 = mean; out[B, ns*C] */
 int gn_segment_pool_fwd(const float* x, int64_t ldx, int32_t C, const int32_t* ptr, int32_t B,
