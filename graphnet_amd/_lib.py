@@ -46,7 +46,7 @@ SIGNATURES = {
     "gn_edgeconv_bwd": (I32, [I32, P, P, P, P, I32, I32, P, I32, I32, P, I64, P, P, I32, P, P, I64, P]),
     "gn_edgeconv_dw2_slabs": (I32, [I32, I32, I32, I32, I32]),
     "gn_edgeconv_dw2": (I32, [I32, P, P, P, P, I32, I32, P, I32, I32, I32, P, I64, P, P, P, P]),
-    "gn_edgeconv_dq_gather": (I32, [I32, P, I32, P, P, I32, P, I64, P]),
+    "gn_edgeconv_dq_gather": (I32, [I32, P, I32, P, P, P, P, I32, P, I64, P]),
     "gn_pack_weights": (I32, [P, I32, P]),
     "gn_segment_pool_fwd": (I32, [P, I64, I32, P, I32, P, I32, P, P, P, P]),
     "gn_segment_pool_bwd": (I32, [P, I32, P, P, I32, P, I32, P, P, P, I64, P, I64, I32, P]),

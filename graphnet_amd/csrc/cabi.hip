@@ -175,8 +175,8 @@ int gn_edgeconv_bwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre,
                                     saved, W2Tp, H2p, dpre, dP, ldp, S(stream)), "gn_edgeconv_bwd");
 }
 int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int32_t* rev_ptr, const int32_t* rev_rows,
-                          int32_t N, void* dQ, int64_t ldq, void* stream) {
-    hipError_t r = gn::launch_dq_gather(mode, dpre, H1p, rev_ptr, rev_rows, N, dQ, ldq, S(stream));
+                          const int32_t* hubs, const int32_t* nhubs, int32_t N, void* dQ, int64_t ldq, void* stream) {
+    hipError_t r = gn::launch_dq_gather(mode, dpre, H1p, rev_ptr, rev_rows, hubs, nhubs, N, dQ, ldq, S(stream));
     if (r == hipErrorInvalidValue) return bad("gn_edgeconv_dq_gather", "need H1p <= 512, H1p%8==0, 16-byte dQ row pitch");
     return fail(r, "gn_edgeconv_dq_gather");
 }

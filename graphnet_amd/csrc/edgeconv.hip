@@ -479,15 +479,17 @@ __device__ __forceinline__ void dq_row_load(const T* row, int col, bool ok, floa
     }
 }
 
+constexpr int DQ_HUB_MIN = 64, DQ_HUB_CAP = 16384;     // = REV_SORT_MIN / REV_SORT_CAP of graph.hip
 template <typename T>
 __global__ __launch_bounds__(256) void dq_gather_kernel(const T* __restrict__ dpre, int H1p,
                                                         const int* __restrict__ rev_ptr, const int* __restrict__ rev_rows,
-                                                        int N, T* __restrict__ dQ, long long ldq) {
+                                                        int N, T* __restrict__ dQ, long long ldq, int skip_hubs) {
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (j >= N) return;
     const int lo = rev_ptr[j], hi = rev_ptr[j + 1];
     const int deg = hi - lo;
+    if (skip_hubs && deg > DQ_HUB_MIN && deg <= DQ_HUB_CAP) return;       // dq_hub_kernel sums this node
     // lane owns columns [8*lane, 8*lane+8) (pass 0) and [512 + 8*lane, ...) is never needed: H1p <= 512
     const int col = lane * 8;
     const bool ok = col < H1p;                                // H1p is a multiple of 8 on this path
@@ -567,6 +569,54 @@ __global__ __launch_bounds__(256) void dq_gather_kernel(const T* __restrict__ dp
         T* dst = dQ + (long long)j * ldq + col;
         store4<T>(dst, acc[0], acc[1], acc[2], acc[3]);
         store4<T>(dst + 4, acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+// Hub nodes (sorted in-edge lists of 65..16384 rows): one 16-wave workgroup per hub.  Wave w sums the row
+// blocks b = w, w+16, ... (8 rows each, loaded together) in ascending order, the 16 partial sums are added
+// in wave order: a fixed order, so the result is reproducible, and 16 x 8 rows are in flight per hub.
+constexpr int DQ_HUB_WAVES = 16;
+template <typename T>
+__global__ __launch_bounds__(DQ_HUB_WAVES * 64) void dq_hub_kernel(const T* __restrict__ dpre, int H1p,
+                                                                    const int* __restrict__ rev_ptr,
+                                                                    const int* __restrict__ rev_rows,
+                                                                    const int* __restrict__ hubs, const int* __restrict__ nhubs,
+                                                                    T* __restrict__ dQ, long long ldq) {
+    __shared__ float part[DQ_HUB_WAVES][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane * 8;
+    const bool ok = col < H1p;
+    const int n = *nhubs;
+    for (int t = blockIdx.x; t < n; t += gridDim.x) {
+        const int j = hubs[t];
+        const int lo = rev_ptr[j], deg = rev_ptr[j + 1] - lo;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+        for (int b0 = wave * 8; b0 < deg; b0 += DQ_HUB_WAVES * 8) {
+            float v[8][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(b0 + u, deg - 1);
+                dq_row_load<T>(dpre + (long long)rev_rows[lo + e] * H1p, col, ok && (b0 + u < deg), v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] += v[u][c];
+        }
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) part[wave][col + c] = acc[c];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < H1p; c += DQ_HUB_WAVES * 64) {
+            float s = part[0][c];
+#pragma unroll
+            for (int w = 1; w < DQ_HUB_WAVES; ++w) s += part[w][c];
+            dQ[(long long)j * ldq + c] = from_f32<T>(s);
+        }
+        __syncthreads();
     }
 }
 
@@ -745,16 +795,26 @@ hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p
 }
 
 // dQ is float in mode 0 and bf16 in mode 1 (like dpre)
-hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows, int N,
-                            void* dQ, long long ldq, hipStream_t st) {
+// hubs / nhubs (optional): the hub list rev_build left behind; those nodes are then summed by 16 waves each
+hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows,
+                            const int* hubs, const int* nhubs, int N, void* dQ, long long ldq, hipStream_t st) {
     if (N == 0) return hipSuccess;
     if (H1p > 512 || (H1p & 7) || (ldq & (mode ? 7 : 3))) return hipErrorInvalidValue;
-    if (mode == 0)
+    const int skip = (hubs && nhubs) ? 1 : 0;
+    const dim3 hgrid(256), hblock(DQ_HUB_WAVES * 64);
+    if (mode == 0) {
         hipLaunchKernelGGL((dq_gather_kernel<float>), dim3(cdiv__(N, 4)), dim3(256), 0, st, (const float*)dpre, H1p,
-                           rev_ptr, rev_rows, N, (float*)dQ, ldq);
-    else
+                           rev_ptr, rev_rows, N, (float*)dQ, ldq, skip);
+        if (skip)
+            hipLaunchKernelGGL((dq_hub_kernel<float>), hgrid, hblock, 0, st, (const float*)dpre, H1p, rev_ptr, rev_rows,
+                               hubs, nhubs, (float*)dQ, ldq);
+    } else {
         hipLaunchKernelGGL((dq_gather_kernel<__bf16>), dim3(cdiv__(N, 4)), dim3(256), 0, st, (const __bf16*)dpre, H1p,
-                           rev_ptr, rev_rows, N, (__bf16*)dQ, ldq);
+                           rev_ptr, rev_rows, N, (__bf16*)dQ, ldq, skip);
+        if (skip)
+            hipLaunchKernelGGL((dq_hub_kernel<__bf16>), hgrid, hblock, 0, st, (const __bf16*)dpre, H1p, rev_ptr, rev_rows,
+                               hubs, nhubs, (__bf16*)dQ, ldq);
+    }
     return hipGetLastError();
 }
 

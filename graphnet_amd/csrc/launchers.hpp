@@ -43,8 +43,8 @@ hipError_t launch_edge_bwd(int mode, const EdgeGraph& g, const void* PQ, int H1p
 int edge_dw2_slabs(int mode, int N, int K, int H1p, int H2);
 hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout,
                            long long ldg, void* saved, float* slab, float* db2_part, hipStream_t st);
-hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows, int N,
-                            void* dQ, long long ldq, hipStream_t st);
+hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows,
+                            const int* hubs, const int* nhubs, int N, void* dQ, long long ldq, hipStream_t st);
 // pool.hip
 hipError_t launch_pack_weights(const long long* desc, int ndesc, hipStream_t st);
 hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr, int B, const int* codes, int ns,

@@ -101,6 +101,8 @@ class NeighbourTable:
     K: int
     rev_ptr: Optional[Tensor] = None
     rev_rows: Optional[Tensor] = None
+    rev_hubs: Optional[Tensor] = None      # nodes with 65..16384 in-edges (sorted lists) ...
+    rev_nhubs: Optional[Tensor] = None     # ... and their number (int32[>=1], element 0)
 
     @property
     def N(self) -> int:
@@ -131,6 +133,7 @@ class NeighbourTable:
             _lib.check(L.gn_rev_build(_p(self.nbr), N, self.K, _p(self.ovf_src), _p(self.ovf_cnt), _p(rev_ptr),
                                       _p(cursor), _p(tmp), _p(rev_rows), _st()))
         self.rev_ptr, self.rev_rows = rev_ptr, rev_rows
+        self.rev_hubs, self.rev_nhubs = cursor, tmp        # hub list / its length, left there by gn_rev_build
 
     def edge_index(self) -> Tensor:
         """Materialise PyG-style ``edge_index[2,E]`` int64 (API boundary only; syncs)."""
@@ -410,7 +413,8 @@ def edgeconv_dq_gather(mode: int, g: NeighbourTable, dpre: Tensor, H1p: int, dQ:
     g.build_reverse()
     _need(dQ, act_dtype(mode), "dQ")
     with _timed("edgeconv_dq_gather"):
-        _lib.check(_lib.lib().gn_edgeconv_dq_gather(mode, _p(dpre), H1p, _p(g.rev_ptr), _p(g.rev_rows), g.N, _p(dQ),
+        _lib.check(_lib.lib().gn_edgeconv_dq_gather(mode, _p(dpre), H1p, _p(g.rev_ptr), _p(g.rev_rows),
+                                                    _p(g.rev_hubs), _p(g.rev_nhubs), g.N, _p(dQ),
                                                     _rows(dQ, "dQ"), _st()))
 
 

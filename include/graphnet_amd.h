@@ -140,9 +140,13 @@ int gn_edgeconv_bwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre,
                     const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H2,
                     const void* gout, int64_t ldg, const void* saved, const void* W2Tp, int32_t H2p,
                     void* dpre, void* dP, int64_t ldp, void* stream);
-/* dQ[j] (T[N, ldq]) = sum of dpre rows that gathered from j (ascending row id, fp32 accumulation) */
+/* dQ[j] (T[N, ldq]) = sum of dpre rows that gathered from j (ascending row id, fp32 accumulation).
+ * hubs / nhubs (optional, may be NULL): what gn_rev_build leaves in its `cursor` / `tmp[0]` workspace - the
+ * nodes with 65..16384 in-edges (sorted lists); they are then summed by a 16-wave workgroup each, in a
+ * fixed block order, instead of by one wave. */
 int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int32_t* rev_ptr,
-                          const int32_t* rev_rows, int32_t N, void* dQ, int64_t ldq, void* stream);
+                          const int32_t* rev_rows, const int32_t* hubs, const int32_t* nhubs, int32_t N,
+                          void* dQ, int64_t ldq, void* stream);
 
 /* ---- operand copies of the weights ------------------------------------------------------- */
 /* One launch rewrites every padded / transposed / bf16 copy of the weights the kernels above consume
