@@ -441,24 +441,26 @@ __global__ __launch_bounds__(256) void edges_to_table(const long long* __restric
 }
 
 // ---------------------------------------------------------------- global variables
-// One wave per event.  out[g, 0:F] = mean_i x[i,:], out[g, F+c] = homophily of column c
+// One workgroup (4 waves) per event.  out[g, 0:F] = mean_i x[i,:], out[g, F+c] = homophily of column c
 // (c = 0..3; exact float equality over edges j->i of the event), out[g, F+4] = log10(n).
+// Thread t takes pulses lo+t, lo+t+256, ...; lanes are combined by a butterfly, the 4 waves in wave order.
 __global__ __launch_bounds__(256) void globals_kernel(
     const float* __restrict__ x, long long ldx, int F, const int* __restrict__ ptr, int B,
     const int* __restrict__ nbr, const int* __restrict__ ovf, int K,
     const int* __restrict__ n_pulses, float* __restrict__ out)
 {
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (g >= B) return;
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lo = ptr[g], hi = ptr[g + 1];
     constexpr int FMAX = 32;
+    __shared__ float s_sum[4][FMAX];
+    __shared__ int s_cnt[4][5];
     float sum[FMAX];
 #pragma unroll
     for (int f = 0; f < FMAX; ++f) sum[f] = 0.0f;
     int match[4] = {0, 0, 0, 0};
     int edges = 0;
-    for (int i = lo + lane; i < hi; i += 64) {
+    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) {
         const float* xi = x + (long long)i * ldx;
 #pragma unroll
         for (int f = 0; f < FMAX; ++f) if (f < F) sum[f] += xi[f];
@@ -485,13 +487,21 @@ __global__ __launch_bounds__(256) void globals_kernel(
         edges += __shfl_xor(edges, o);
     }
     if (lane == 0) {
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) s_sum[wave][f] = sum[f];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_cnt[wave][c] = match[c];
+        s_cnt[wave][4] = edges;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         const int G = F + 5;
         float* o = out + (long long)g * G;
         const float cnt = (float)max(hi - lo, 1);
-#pragma unroll
-        for (int f = 0; f < FMAX; ++f) if (f < F) o[f] = sum[f] / cnt;
-        const float ne = (float)max(edges, 1);
-        for (int c = 0; c < 4; ++c) o[F + c] = (float)match[c] / ne;
+        for (int f = 0; f < F; ++f) o[f] = (((s_sum[0][f] + s_sum[1][f]) + s_sum[2][f]) + s_sum[3][f]) / cnt;
+        const int ed = s_cnt[0][4] + s_cnt[1][4] + s_cnt[2][4] + s_cnt[3][4];
+        const float ne = (float)max(ed, 1);
+        for (int c = 0; c < 4; ++c) o[F + c] = (float)(s_cnt[0][c] + s_cnt[1][c] + s_cnt[2][c] + s_cnt[3][c]) / ne;
         o[F + 4] = log10f((float)n_pulses[g]);
     }
 }
@@ -635,7 +645,7 @@ hipError_t launch_edges_to_table(const long long* edge_index, long long E, int N
 hipError_t launch_globals(const float* x, long long ldx, int F, const int* ptr, int B, const int* nbr, const int* ovf,
                           int K, const int* n_pulses, float* out, hipStream_t st) {
     if (B == 0) return hipSuccess;
-    hipLaunchKernelGGL(globals_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, ldx, F, ptr, B, nbr, ovf, K, n_pulses, out);
+    hipLaunchKernelGGL(globals_kernel, dim3(B), dim3(256), 0, st, x, ldx, F, ptr, B, nbr, ovf, K, n_pulses, out);
     return hipGetLastError();
 }
 hipError_t launch_concat_globals(const float* x, long long ldx, int F, const float* gv, int G, const int* batch, int N,

@@ -12,39 +12,51 @@ namespace gn {
 // scheme codes: 0 = min, 1 = max, 2 = sum, 3 = mean   (order given by the caller)
 struct PoolSchemes { int code[4]; int n; };
 
-__global__ __launch_bounds__(256) void segment_pool_fwd_kernel(
+// grid.x = event, grid.y = 256-column group; 1024 threads = 4 row groups x 256 columns: group r streams the
+// event's rows r, r+4, ... (two in flight), the groups are combined through LDS in group order - min / max
+// keep the FIRST occurrence (smaller row index on ties), exactly what a sequential scan returns.
+constexpr int POOL_RG = 4;
+__global__ __launch_bounds__(256 * POOL_RG) void segment_pool_fwd_kernel(
     const float* __restrict__ x, long long ldx, int C, const int* __restrict__ ptr, int B,
     PoolSchemes sch, float* __restrict__ out /*[B, n*C]*/, int* __restrict__ argmin, int* __restrict__ argmax)
 {
-    // grid.x = event, grid.y = 256-column group; thread = column; 4 independent rows in flight
+    __shared__ float s_mn[POOL_RG][256], s_mx[POOL_RG][256], s_sm[POOL_RG][256];
+    __shared__ int s_amn[POOL_RG][256], s_amx[POOL_RG][256];
     const int g = blockIdx.x;
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= C) return;
+    const int tc = threadIdx.x & 255, rg = threadIdx.x >> 8;
+    const int c = blockIdx.y * 256 + tc;
+    const int cc = c < C ? c : 0;                       // clamped column: every thread reaches the barrier
     const int lo = ptr[g], hi = ptr[g + 1];
-    float mn = 0.0f, mx = 0.0f, sm = 0.0f;
-    int amn = -1, amx = -1;
-    if (hi > lo) {
-        mn = mx = sm = x[(long long)lo * ldx + c];
-        amn = amx = lo;
-        int i = lo + 1;
-        for (; i + 3 < hi; i += 4) {
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = x[(long long)(i + u) * ldx + c];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                sm += v[u];
-                if (v[u] < mn) { mn = v[u]; amn = i + u; }
-                if (v[u] > mx) { mx = v[u]; amx = i + u; }
-            }
-        }
-        for (; i < hi; ++i) {
-            const float v = x[(long long)i * ldx + c];
-            sm += v;
-            if (v < mn) { mn = v; amn = i; }
-            if (v > mx) { mx = v; amx = i; }
-        }
+    float mn = 3.0e38f, mx = -3.0e38f, sm = 0.0f;
+    int amn = 0x7fffffff, amx = 0x7fffffff;
+    int i = lo + rg;
+    for (; i + POOL_RG < hi; i += 2 * POOL_RG) {
+        const float v0 = x[(long long)i * ldx + cc], v1 = x[(long long)(i + POOL_RG) * ldx + cc];
+        sm += v0;
+        if (v0 < mn) { mn = v0; amn = i; }
+        if (v0 > mx) { mx = v0; amx = i; }
+        sm += v1;
+        if (v1 < mn) { mn = v1; amn = i + POOL_RG; }
+        if (v1 > mx) { mx = v1; amx = i + POOL_RG; }
     }
+    for (; i < hi; i += POOL_RG) {
+        const float v = x[(long long)i * ldx + cc];
+        sm += v;
+        if (v < mn) { mn = v; amn = i; }
+        if (v > mx) { mx = v; amx = i; }
+    }
+    s_mn[rg][tc] = mn; s_mx[rg][tc] = mx; s_sm[rg][tc] = sm; s_amn[rg][tc] = amn; s_amx[rg][tc] = amx;
+    __syncthreads();
+    if (rg != 0 || c >= C) return;
+#pragma unroll
+    for (int r = 1; r < POOL_RG; ++r) {
+        const float m2 = s_mn[r][tc], x2 = s_mx[r][tc];
+        const int a2 = s_amn[r][tc], b2 = s_amx[r][tc];
+        if (m2 < mn || (m2 == mn && a2 < amn)) { mn = m2; amn = a2; }
+        if (x2 > mx || (x2 == mx && b2 < amx)) { mx = x2; amx = b2; }
+        sm += s_sm[r][tc];
+    }
+    if (hi <= lo) { mn = mx = sm = 0.0f; amn = amx = -1; }          // empty segment -> 0
     const float mean = sm / (float)max(hi - lo, 1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -174,7 +186,7 @@ hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr,
     PoolSchemes s;
     s.n = ns;
     for (int i = 0; i < 4; ++i) s.code[i] = i < ns ? codes[i] : 0;
-    hipLaunchKernelGGL(segment_pool_fwd_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, st, x, ldx, C, ptr, B, s, out, argmin, argmax);
+    hipLaunchKernelGGL(segment_pool_fwd_kernel, dim3(B, (C + 255) / 256), dim3(256 * POOL_RG), 0, st, x, ldx, C, ptr, B, s, out, argmin, argmax);
     return hipGetLastError();
 }
 
