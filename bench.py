@@ -125,11 +125,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal knobs (one-GPU box only, never set by the driver): GN_BENCH_REHEARSE=1 puts every rank on
+    # cuda:0 and exchanges gradients over gloo, to exercise the multi-rank control flow without a second GPU.
+    rehearse = os.environ.get("GN_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
+    torch.cuda.set_device(local)                         # before the process group: RCCL binds to the current device
+    dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from graphnet_amd import _lib, ops
     from graphnet_amd.parallel import FlatGradAllReduce, broadcast_parameters
@@ -181,12 +189,10 @@ def main():
     # Untimed ramp-up before the W warm-up steps: the first ~0.3 s of sustained load run at ~25 % lower
     # throughput (GPU clock / power-state ramp and allocator growth: 10.0 ms/step with 5 warm-up steps vs
     # 7.5 ms/step with 40), so a short warm-up would time the ramp instead of the steady state.
-    t_ramp = time.perf_counter()
-    n_ramp = 0
-    while n_ramp < 30 or time.perf_counter() - t_ramp < 0.75:
+    # A FIXED number of steps: every step contains the gradient all-reduce, so all ranks must run the same count.
+    for i in range(80):
         step()
-        n_ramp += 1
-        if n_ramp % 10 == 0:
+        if i % 10 == 9:
             torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
