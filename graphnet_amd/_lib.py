@@ -33,6 +33,7 @@ SIGNATURES = {
     "gn_table_to_edge_index": (I32, [P, P, I32, I32, P, I64, P, P]),
     "gn_edge_index_to_table": (I32, [P, I64, I32, I32, P, P, P, P, P]),
     "gn_ptr_to_batch": (I32, [P, I32, P, P]),
+    "gn_standardize": (I32, [P, I64, I32, I32, P, P, P, P]),
     "gn_graph_globals": (I32, [P, I64, I32, P, I32, P, P, I32, P, P, P]),
     "gn_concat_globals": (I32, [P, I64, I32, P, I32, P, I32, P, I32, I32, P]),
     "gn_linear_fwd": (I32, [I32, I32, P, I32, P, P, P, I32, P, I32, I32, I32, P, P, I32, I64, I32, I32, P, I64, I32, P]),

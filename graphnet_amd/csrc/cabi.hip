@@ -89,6 +89,13 @@ int gn_edge_index_to_table(const int64_t* edge_index, int64_t E, int32_t N, int3
 int gn_ptr_to_batch(const int32_t* ptr, int32_t B, int32_t* batch, void* stream) {
     return fail(gn::launch_ptr_to_batch(ptr, B, batch, S(stream)), "gn_ptr_to_batch");
 }
+int gn_standardize(float* x, int64_t ldx, int32_t N, int32_t F, const int32_t* nops_host, const int32_t* op_host,
+                   const float* const_host, void* stream) {
+    if (!nops_host || !op_host || !const_host || ldx < F) return bad("gn_standardize", "programs / pitch");
+    hipError_t r = gn::launch_standardize(x, ldx, N, F, nops_host, op_host, const_host, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_standardize", "need 1 <= F <= 32, <= 3 steps per column, op codes 0..4");
+    return fail(r, "gn_standardize");
+}
 int gn_graph_globals(const float* x, int64_t ldx, int32_t F, const int32_t* ptr, int32_t B, const int32_t* nbr,
                      const int32_t* ovf, int32_t K, const int32_t* n_pulses, float* out, void* stream) {
     if (F < 4 || F > 32 || ldx < F) return bad("gn_graph_globals", "need 4 <= F <= 32 (columns 0-3 = x,y,z,t)");

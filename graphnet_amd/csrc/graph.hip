@@ -440,6 +440,34 @@ __global__ __launch_bounds__(256) void edges_to_table(const long long* __restric
     else atomicAdd(err, 1);                                        // degree > K+1
 }
 
+// ---------------------------------------------------------------- feature standardisation
+// Detector._standardize (models/detector/detector.py:64-77) for a whole batch in one pass, in place: column f
+// runs its program of up to 3 steps (add / sub / mul / div / log10 with a constant), in fp32, in the order
+// and with the operations of the reference's per-column lambdas (icecube.py:21-48, prometheus.py:11-39).
+constexpr int STD_MAXF = 32, STD_MAXOPS = 3;
+struct StdProgram { int nops[STD_MAXF]; int op[STD_MAXF][STD_MAXOPS]; float c[STD_MAXF][STD_MAXOPS]; };
+__global__ __launch_bounds__(256) void standardize_kernel(float* __restrict__ x, long long ldx, int N, int F, StdProgram p) {
+#pragma clang fp contract(off)
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(t / F), f = (int)(t % F);
+    if (i >= N) return;
+    float v = x[(long long)i * ldx + f];
+    const int n = p.nops[f];
+    for (int k = 0; k < STD_MAXOPS; ++k) {
+        if (k < n) {
+            const float c = p.c[f][k];
+            switch (p.op[f][k]) {
+                case 0: v = v + c; break;
+                case 1: v = v - c; break;
+                case 2: v = v * c; break;
+                case 3: v = v / c; break;
+                default: v = log10f(v); break;
+            }
+        }
+    }
+    x[(long long)i * ldx + f] = v;
+}
+
 // ---------------------------------------------------------------- global variables
 // One workgroup (4 waves) per event.  out[g, 0:F] = mean_i x[i,:], out[g, F+c] = homophily of column c
 // (c = 0..3; exact float equality over edges j->i of the event), out[g, F+4] = log10(n).
@@ -656,6 +684,23 @@ hipError_t launch_concat_globals(const float* x, long long ldx, int F, const flo
         hipLaunchKernelGGL(concat_globals<__bf16>, grid, block, 0, st, x, ldx, F, gv, G, batch, N, (__bf16*)x0, ld0);
     else
         hipLaunchKernelGGL(concat_globals<float>, grid, block, 0, st, x, ldx, F, gv, G, batch, N, (float*)x0, ld0);
+    return hipGetLastError();
+}
+hipError_t launch_standardize(float* x, long long ldx, int N, int F, const int* nops, const int* op, const float* c,
+                              hipStream_t st) {
+    if (F < 1 || F > STD_MAXF) return hipErrorInvalidValue;
+    if (N == 0) return hipSuccess;
+    StdProgram p;
+    for (int f = 0; f < STD_MAXF; ++f) {
+        p.nops[f] = f < F ? nops[f] : 0;
+        if (p.nops[f] < 0 || p.nops[f] > STD_MAXOPS) return hipErrorInvalidValue;
+        for (int k = 0; k < STD_MAXOPS; ++k) {
+            p.op[f][k] = (f < F && k < p.nops[f]) ? op[f * STD_MAXOPS + k] : 0;
+            p.c[f][k] = (f < F && k < p.nops[f]) ? c[f * STD_MAXOPS + k] : 0.0f;
+            if (p.op[f][k] < 0 || p.op[f][k] > 4) return hipErrorInvalidValue;
+        }
+    }
+    hipLaunchKernelGGL(standardize_kernel, dim3(cdiv((long long)N * F, 256)), dim3(256), 0, st, x, ldx, N, F, p);
     return hipGetLastError();
 }
 hipError_t launch_ptr_to_batch(const int* ptr, int B, int* batch, hipStream_t st) {

@@ -22,6 +22,8 @@ hipError_t launch_globals(const float* x, long long ldx, int F, const int* ptr, 
 hipError_t launch_concat_globals(const float* x, long long ldx, int F, const float* gv, int G, const int* batch, int N,
                                  void* x0, int ld0, int out_lowp, hipStream_t st);
 hipError_t launch_ptr_to_batch(const int* ptr, int B, int* batch, hipStream_t st);
+hipError_t launch_standardize(float* x, long long ldx, int N, int F, const int* nops, const int* op, const float* c,
+                              hipStream_t st);
 // gemm.hip
 hipError_t launch_gemm_nt(int mode, const Segs& a, int a_lowp, int M, const void* Wp, int Kp, int Npad, int Nreal,
                           const Epi& epi, void* C, long long ldc, int out_lowp, hipStream_t st);

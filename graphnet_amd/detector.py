@@ -6,10 +6,34 @@ column by column, ``KeyError`` for an unknown feature name) and the scaling cons
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List
+from typing import Callable, Dict, List, Sequence, Tuple
 
 import torch
 from torch import Tensor
+
+
+# A standardisation is a short program of (op, constant) steps applied left to right in fp32 - the same
+# expression, operation by operation, as the reference's lambdas (``x / 500.0`` is a division, never a
+# multiplication by the reciprocal: the standardised coordinates decide the k-NN graph bit for bit).
+Op = Tuple[str, float]
+_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "log10": 4}
+
+
+def _apply_ops(x: Tensor, prog: Sequence[Op]) -> Tensor:
+    for op, c in prog:
+        if op == "add":
+            x = x + c
+        elif op == "sub":
+            x = x - c
+        elif op == "mul":
+            x = x * c
+        elif op == "div":
+            x = x / c
+        elif op == "log10":
+            x = torch.log10(x)
+        else:
+            raise ValueError(op)
+    return x
 
 
 class Detector:
@@ -19,8 +43,12 @@ class Detector:
     string_id_column = "string"
     sensor_id_column = "sensor_id"
 
-    def feature_map(self) -> Dict[str, Callable[[Tensor], Tensor]]:
+    def feature_ops(self) -> Dict[str, List[Op]]:
+        """feature name -> program (``[]`` = identity)."""
         raise NotImplementedError
+
+    def feature_map(self) -> Dict[str, Callable[[Tensor], Tensor]]:
+        return {k: (lambda x, p=tuple(v): _apply_ops(x, p)) for k, v in self.feature_ops().items()}
 
     def __call__(self, input_features: Tensor, input_feature_names: List[str]) -> Tensor:
         return self._standardize(input_features, input_feature_names)
@@ -28,86 +56,58 @@ class Detector:
     forward = __call__
 
     def _standardize(self, input_features: Tensor, input_feature_names: List[str]) -> Tensor:
-        fmap = self.feature_map()
-        for idx, feature in enumerate(input_feature_names):
-            if feature not in fmap:
+        """In place, column by column (``detector.py:64-77``).  A HIP tensor is standardised by one kernel
+        (``gn_standardize``) running the same programs; a CPU tensor with torch ops."""
+        fops = self.feature_ops()
+        for feature in input_feature_names:
+            if feature not in fops:
                 raise KeyError(f"No Standardization function found for '{feature}'")
-            input_features[:, idx] = fmap[feature](input_features[:, idx])
+        if input_features.is_cuda and input_features.dtype == torch.float32 and input_features.dim() == 2:
+            from . import ops
+            ops.standardize(input_features, [fops[f] for f in input_feature_names])
+            return input_features
+        for idx, feature in enumerate(input_feature_names):
+            input_features[:, idx] = _apply_ops(input_features[:, idx], fops[feature])
         return input_features
-
-    @staticmethod
-    def _identity(x: Tensor) -> Tensor:
-        return x
 
 
 class IceCube86(Detector):
     xyz = ["dom_x", "dom_y", "dom_z"]
 
-    def feature_map(self):
+    def feature_ops(self):
+        xyz = [("div", 500.0)]
         return {
-            "dom_x": self._dom_xyz, "dom_y": self._dom_xyz, "dom_z": self._dom_xyz,
-            "dom_time": self._dom_time, "charge": self._charge, "rde": self._rde,
-            "pmt_area": self._pmt_area, "hlc": self._identity,
+            "dom_x": xyz, "dom_y": xyz, "dom_z": xyz,
+            "dom_time": [("sub", 1.0e04), ("div", 3.0e4)], "charge": [("log10", 0.0)],
+            "rde": [("sub", 1.25), ("div", 0.25)], "pmt_area": [("div", 0.05)], "hlc": [],
         }
-
-    @staticmethod
-    def _dom_xyz(x):
-        return x / 500.0
-
-    @staticmethod
-    def _dom_time(x):
-        return (x - 1.0e04) / 3.0e4
-
-    @staticmethod
-    def _charge(x):
-        return torch.log10(x)
-
-    @staticmethod
-    def _rde(x):
-        return (x - 1.25) / 0.25
-
-    @staticmethod
-    def _pmt_area(x):
-        return x / 0.05
 
 
 class IceCubeDeepCore(IceCube86):
-    def feature_map(self):
+    def feature_ops(self):
         return {
-            "dom_x": self._dom_xy, "dom_y": self._dom_xy, "dom_z": self._dom_z,
-            "dom_time": self._dom_time_dc, "charge": self._identity, "rde": self._rde,
-            "pmt_area": self._pmt_area, "hlc": self._identity,
+            "dom_x": [("div", 100.0)], "dom_y": [("div", 100.0)], "dom_z": [("add", 350.0), ("div", 100.0)],
+            "dom_time": [("div", 1.05e04), ("sub", 1.0), ("mul", 20.0)], "charge": [],
+            "rde": [("sub", 1.25), ("div", 0.25)], "pmt_area": [("div", 0.05)], "hlc": [],
         }
-
-    @staticmethod
-    def _dom_xy(x):
-        return x / 100.0
-
-    @staticmethod
-    def _dom_z(x):
-        return (x + 350.0) / 100.0
-
-    @staticmethod
-    def _dom_time_dc(x):
-        return ((x / 1.05e04) - 1.0) * 20.0
 
 
 class IceCubeUpgrade(Detector):
     xyz = ["dom_x", "dom_y", "dom_z"]
 
-    def feature_map(self):
+    def feature_ops(self):
         return {
-            "dom_x": lambda x: x / 500.0, "dom_y": lambda x: x / 500.0, "dom_z": lambda x: x / 500.0,
-            "dom_time": lambda x: (x / 2e04) - 1.0,
-            "charge": lambda x: torch.log10(x) / 2.0,
-            "rde": self._identity,
-            "pmt_area": lambda x: x / 0.05,
-            "string": lambda x: (x - 50.0) / 50.0,
-            "pmt_number": lambda x: x / 20.0,
-            "dom_number": lambda x: (x - 60.0) / 60.0,
-            "pmt_dir_x": self._identity, "pmt_dir_y": self._identity, "pmt_dir_z": self._identity,
-            "dom_type": lambda x: x / 130.0,
-            "hlc": self._identity,
+            "dom_x": [("div", 500.0)], "dom_y": [("div", 500.0)], "dom_z": [("div", 500.0)],
+            "dom_time": [("div", 2e04), ("sub", 1.0)],
+            "charge": [("log10", 0.0), ("div", 2.0)],
+            "rde": [],
+            "pmt_area": [("div", 0.05)],
+            "string": [("sub", 50.0), ("div", 50.0)],
+            "pmt_number": [("div", 20.0)],
+            "dom_number": [("sub", 60.0), ("div", 60.0)],
+            "pmt_dir_x": [], "pmt_dir_y": [], "pmt_dir_z": [],
+            "dom_type": [("div", 130.0)],
+            "hlc": [],
         }
 
 
@@ -115,10 +115,10 @@ class ORCA150SuperDense(Detector):
     xyz = ["sensor_pos_x", "sensor_pos_y", "sensor_pos_z"]
     string_id_column = "sensor_string_id"
 
-    def feature_map(self):
+    def feature_ops(self):
         return {
-            "sensor_pos_x": lambda x: x / 100, "sensor_pos_y": lambda x: x / 100,
-            "sensor_pos_z": lambda x: (x + 350) / 100, "t": lambda x: x / 1.05e04,
+            "sensor_pos_x": [("div", 100)], "sensor_pos_y": [("div", 100)],
+            "sensor_pos_z": [("add", 350), ("div", 100)], "t": [("div", 1.05e04)],
         }
 
 

@@ -215,6 +215,30 @@ def ptr_to_batch(ptr: Tensor, N: int) -> Tensor:
     return batch
 
 
+_STD_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "log10": 4}
+
+
+def standardize(x: Tensor, programs: Sequence[Sequence[Tuple[str, float]]]) -> Tensor:
+    """In-place per-column standardisation of ``x[N, F]`` (``gn_standardize``); ``programs[f]`` = up to three
+    ``(op, constant)`` steps with op in add / sub / mul / div / log10."""
+    _need(x, torch.float32, "x")
+    F = len(programs)
+    if int(x.shape[1]) != F:
+        raise ValueError("one program per column")
+    nops = (ctypes.c_int32 * F)(*[len(p) for p in programs])
+    op = (ctypes.c_int32 * (3 * F))()
+    cst = (ctypes.c_float * (3 * F))()
+    for f, prog in enumerate(programs):
+        if len(prog) > 3:
+            raise ValueError("at most 3 steps per column")
+        for k, (name, c) in enumerate(prog):
+            op[3 * f + k] = _STD_OPS[name]
+            cst[3 * f + k] = float(c)
+    _lib.check(_lib.lib().gn_standardize(_p(x), _rows(x, "x"), int(x.shape[0]), F, ctypes.cast(nops, ctypes.c_void_p),
+                                         ctypes.cast(op, ctypes.c_void_p), ctypes.cast(cst, ctypes.c_void_p), _st()))
+    return x
+
+
 def graph_globals(x: Tensor, ptr: Tensor, g: NeighbourTable, n_pulses: Tensor) -> Tensor:
     _need(x, torch.float32, "x"); _need(n_pulses, torch.int32, "n_pulses")
     B, F = int(ptr.shape[0]) - 1, int(x.shape[1])

@@ -75,6 +75,12 @@ int gn_edge_index_to_table(const int64_t* edge_index, int64_t E, int32_t N, int3
 
 int gn_ptr_to_batch(const int32_t* ptr, int32_t B, int32_t* batch, void* stream);
 
+/* Detector._standardize (models/detector/detector.py:64-77; constants icecube.py:21-48, prometheus.py:11-39)
+ * for the whole batch, in place: column f of x[N, ldx] runs nops_host[f] <= 3 steps, step k = op_host[3f+k]
+ * (0 add, 1 sub, 2 mul, 3 div, 4 log10) with constant const_host[3f+k], fp32, no re-association.  HOST arrays. */
+int gn_standardize(float* x, int64_t ldx, int32_t N, int32_t F, const int32_t* nops_host,
+                   const int32_t* op_host, const float* const_host, void* stream);
+
 /* DynEdge._calculate_global_variables (models/gnn/dynedge.py:266-293; homophily:
  * models/utils.py:13-29): out[B, F+5] = [mean_F | h_x h_y h_z h_t | log10 n_pulses] */
 int gn_graph_globals(const float* x, int64_t ldx, int32_t F, const int32_t* ptr, int32_t B,

@@ -171,6 +171,31 @@ def test_dq_gather_hub_nodes(oracle, name, mode):
     assert rel_err(dQ, ref) < (1e-5 if mode == 0 else 1e-2)
 
 
+def test_standardize_on_device_matches_host(oracle):
+    """Detector._standardize as one HIP kernel: every non-log column bit-identical to the host expression
+    (they decide the k-NN graph), log10 columns to fp32 rounding of the device libm."""
+    import graphnet_amd as g
+    rng = np.random.default_rng(3)
+    for det, names in ((g.IceCube86(), ["dom_x", "dom_y", "dom_z", "dom_time", "charge", "rde", "pmt_area"]),
+                       (g.IceCubeDeepCore(), ["dom_x", "dom_y", "dom_z", "dom_time", "charge", "rde", "pmt_area", "hlc"]),
+                       (g.IceCubeUpgrade(), ["dom_x", "dom_y", "dom_z", "dom_time", "charge", "rde", "pmt_area", "string",
+                                             "pmt_number", "dom_number", "pmt_dir_x", "pmt_dir_y", "pmt_dir_z", "dom_type"]),
+                       (g.Prometheus(), ["sensor_pos_x", "sensor_pos_y", "sensor_pos_z", "t"])):
+        F = len(names)
+        raw = torch.from_numpy(rng.uniform(-600, 600, size=(1000, F)).astype(np.float32))
+        if "charge" in names:
+            raw[:, names.index("charge")] = torch.from_numpy(rng.lognormal(0.3, 0.9, 1000).astype(np.float32))
+        host = det(raw.clone(), names)
+        dev = det(raw.clone().to(DEV), names).cpu()
+        for f, nm in enumerate(names):
+            if any(op == "log10" for op, _ in det.feature_ops()[nm]):
+                assert torch.allclose(dev[:, f], host[:, f], rtol=2e-6, atol=1e-7), nm
+            else:
+                assert torch.equal(dev[:, f], host[:, f]), nm
+    with pytest.raises(KeyError):
+        g.IceCube86()(raw.to(DEV), ["nope"] * F)
+
+
 # ------------------------------------------------------------------------------ globals
 def test_graph_globals(oracle):
     from graphnet_amd import ops
