@@ -188,6 +188,41 @@ int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int
     return fail(r, "gn_edgeconv_dq_gather");
 }
 
+int gn_edge_rows(const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src, const int32_t* ovf_cnt, int32_t N,
+                 int32_t K, int32_t* ic, int32_t* jc, void* stream) {
+    if (K < 1 || K > 32) return bad("gn_edge_rows", "need 1<=K<=32");
+    return fail(gn::launch_edge_rows(make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), gn::edge_slots(K), ic, jc,
+                                     S(stream)), "gn_edge_rows");
+}
+int gn_edge_gather_pre(const float* PQ, int32_t H1p, const int32_t* ic, const int32_t* jc, int64_t rows, float* pre,
+                       void* stream) {
+    hipError_t r = gn::launch_edge_gather_pre(PQ, H1p, ic, jc, rows, pre, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_edge_gather_pre", "H1p % 4 != 0");
+    return fail(r, "gn_edge_gather_pre");
+}
+int gn_rownorm_act_fwd(const float* z, int64_t ldz, int32_t C, const int32_t* valid, const float* gamma, const float* beta,
+                       float eps, int32_t act, float* a, int64_t lda, int32_t Cpad, float* stats, int64_t rows,
+                       void* stream) {
+    hipError_t r = gn::launch_rownorm_act_fwd(z, ldz, C, valid, gamma, beta, eps, act, a, lda, Cpad, stats, rows, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_rownorm_act_fwd", "need 1 <= C <= Cpad <= 512, act in {0,1}, gamma and beta together");
+    return fail(r, "gn_rownorm_act_fwd");
+}
+int gn_rownorm_act_bwd(const float* g, int64_t ldg, const int32_t* gidx, const float* z, int64_t ldz, int32_t C,
+                       const int32_t* valid, const float* gamma, const float* beta, const float* stats, int32_t act,
+                       float* dz, int64_t lddz, int32_t Cpad, float* t_dy, float* t_dyx, int64_t rows, void* stream) {
+    hipError_t r = gn::launch_rownorm_act_bwd(g, ldg, gidx, z, ldz, C, valid, gamma, beta, stats, act, dz, lddz, Cpad, t_dy,
+                                              t_dyx, rows, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_rownorm_act_bwd", "need 1 <= C <= Cpad <= 512, act in {0,1}; LayerNorm needs beta, stats, t_dy, t_dyx");
+    return fail(r, "gn_rownorm_act_bwd");
+}
+int gn_slot_sum(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, const int32_t* ovf_centre,
+                const int32_t* ovf_src, const int32_t* ovf_cnt, int32_t N, int32_t K, float* out, int64_t ldo,
+                void* stream) {
+    if (K < 1 || K > 32) return bad("gn_slot_sum", "need 1<=K<=32");
+    return fail(gn::launch_slot_sum(m, ldm, C, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), gn::edge_slots(K), out,
+                                    ldo, S(stream)), "gn_slot_sum");
+}
+
 int gn_pack_weights(const int64_t* desc, int32_t ndesc, void* stream) {
     if (ndesc < 0 || (ndesc > 0 && !desc)) return bad("gn_pack_weights", "descriptor table");
     return fail(gn::launch_pack_weights(reinterpret_cast<const long long*>(desc), ndesc, S(stream)), "gn_pack_weights");

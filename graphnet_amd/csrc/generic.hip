@@ -1,0 +1,258 @@
+// graphnet_amd/csrc/generic.hip — unfused building blocks for the DynEdge variants the fused kernels do
+// not cover: activation_layer="gelu" and add_norm_layer=True (LayerNorm after every Linear of the edge and
+// post-processing MLPs; models/gnn/dynedge.py:160-167,198-231).
+//
+// With GELU or LayerNorm the backward needs the pre-activations themselves (not one relu bit), and LayerNorm
+// reduces over a whole edge row, so these variants run the edge MLP unfused, on edge-row tensors in HBM:
+//     pre1[r] = P[i_r] + Q[j_r]            edge_gather_pre      (same algebraic split as the fused path)
+//     a1 = act(LN(pre1))                   rownorm_act_fwd
+//     z2 = a1 . W2^T + b2                  gemm (gemm.hip), M = edge rows
+//     m  = act(LN(z2)), 0 on empty slots   rownorm_act_fwd
+//     out[i] = sum_slots m                 slot_sum
+// and the mirror image backwards (rownorm_act_bwd, the same GEMM / wgrad kernels, slot_sum for dP, the
+// reverse-adjacency gather for dQ).  All HBM-bound elementwise / row-reduction kernels: one wave per row.
+#include "common.hpp"
+
+namespace gn {
+
+// ---------------------------------------------------------------- edge row -> (centre, source)
+__global__ __launch_bounds__(256) void edge_rows_kernel(EdgeGraph g, int S, int* __restrict__ ic, int* __restrict__ jc,
+                                                        long long rows) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows) return;
+    const long long main_rows = (long long)g.N * S;
+    int i = 0, j = -1;
+    if (t < main_rows) {
+        i = (int)(t / S);
+        const int s = (int)(t % S);
+        if (s < g.K) j = g.nbr[(long long)i * g.K + s];
+    } else if (g.ovf_cnt && t - main_rows < *g.ovf_cnt) {
+        i = g.ovf_centre[t - main_rows];
+        j = g.ovf_src[t - main_rows];
+    }
+    ic[t] = i;
+    jc[t] = j;
+}
+
+// pre[r, 0:H1p] = P[ic[r]] + Q[jc[r]]  (PQ fp32 [N, 2*H1p]); rows without an edge -> 0
+__global__ __launch_bounds__(256) void edge_gather_pre_kernel(const float* __restrict__ PQ, int H1p,
+                                                              const int* __restrict__ ic, const int* __restrict__ jc,
+                                                              long long rows, float* __restrict__ pre) {
+    const int q4 = H1p >> 2;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long r = t / q4;
+    const int c = (int)(t % q4) * 4;
+    if (r >= rows) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int j = jc[r];
+    if (j >= 0) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(PQ + (long long)ic[r] * 2 * H1p + c);
+        const f32x4 q = *reinterpret_cast<const f32x4*>(PQ + (long long)j * 2 * H1p + H1p + c);
+        v = p + q;
+    }
+    *reinterpret_cast<f32x4*>(pre + r * H1p + c) = v;
+}
+
+// ---------------------------------------------------------------- activations
+// ACT: 0 = relu, 1 = gelu (erf form, torch.nn.GELU() default)
+template <int ACT> __device__ __forceinline__ float act_fwd(float y) {
+    if constexpr (ACT == 0) return fmaxf(y, 0.0f);
+    else return 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+}
+template <int ACT> __device__ __forceinline__ float act_grad(float y) {
+    if constexpr (ACT == 0) return y > 0.0f ? 1.0f : 0.0f;
+    else return 0.5f * (1.0f + erff(y * 0.70710678118654752440f)) + y * 0.39894228040143267794f * expf(-0.5f * y * y);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+constexpr int RN_MAXC = 512;             // columns per row handled by one wave (8 per lane)
+constexpr int RN_PER = RN_MAXC / 64;
+
+// a[r, c] = act(NORM ? LN(z[r, 0:C]) : z[r, c]) for c < C, 0 for C <= c < Cpad and for rows with valid[r] < 0.
+// stats[r] = (mean, rstd) when NORM.  One wave per row.
+template <bool NORM, int ACT>
+__global__ __launch_bounds__(256) void rownorm_act_fwd_kernel(
+    const float* __restrict__ z, long long ldz, int C, const int* __restrict__ valid,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    float* __restrict__ a, long long lda, int Cpad, float* __restrict__ stats, long long rows)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const bool ok = !valid || valid[r] >= 0;
+    float v[RN_PER];
+#pragma unroll
+    for (int k = 0; k < RN_PER; ++k) {
+        const int c = lane + 64 * k;
+        v[k] = (ok && c < C) ? z[r * ldz + c] : 0.0f;
+    }
+    float mean = 0.0f, rstd = 1.0f;
+    if constexpr (NORM) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < RN_PER; ++k) s += v[k];
+        mean = wave_sum(s) / (float)C;
+        float q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < RN_PER; ++k) {
+            const int c = lane + 64 * k;
+            const float d = c < C ? v[k] - mean : 0.0f;
+            q += d * d;
+        }
+        rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        if (lane == 0 && stats) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+    }
+#pragma unroll
+    for (int k = 0; k < RN_PER; ++k) {
+        const int c = lane + 64 * k;
+        if (c < Cpad) {
+            float o = 0.0f;
+            if (ok && c < C) {
+                float y = v[k];
+                if constexpr (NORM) y = (y - mean) * rstd * gamma[c] + beta[c];
+                o = act_fwd<ACT>(y);
+            }
+            a[r * lda + c] = o;
+        }
+    }
+}
+
+// Backward of the above.  g: upstream gradient of a, row gidx ? gidx[r] : r of g[., ldg] (a per-centre gradient
+// is broadcast to the centre's edge rows through gidx = ic).  dz[r, 0:Cpad] (0 in the pad and on invalid rows).
+// NORM: t_dy[r, c] = dL/dLN-output, t_dyx[r, c] = that times xhat (their column sums are dbeta, dgamma).
+template <bool NORM, int ACT>
+__global__ __launch_bounds__(256) void rownorm_act_bwd_kernel(
+    const float* __restrict__ g, long long ldg, const int* __restrict__ gidx,
+    const float* __restrict__ z, long long ldz, int C, const int* __restrict__ valid,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats,
+    float* __restrict__ dz, long long lddz, int Cpad, float* __restrict__ t_dy, float* __restrict__ t_dyx, long long rows)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const bool ok = !valid || valid[r] >= 0;
+    const long long gr = gidx ? (long long)gidx[r] : r;
+    float mean = 0.0f, rstd = 1.0f;
+    if constexpr (NORM) { mean = stats[2 * r]; rstd = stats[2 * r + 1]; }
+    float xh[RN_PER], dy[RN_PER];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < RN_PER; ++k) {
+        const int c = lane + 64 * k;
+        xh[k] = 0.0f; dy[k] = 0.0f;
+        if (ok && c < C) {
+            const float zz = z[r * ldz + c];
+            float y = zz;
+            if constexpr (NORM) { xh[k] = (zz - mean) * rstd; y = xh[k] * gamma[c] + beta[c]; }
+            dy[k] = g[gr * ldg + c] * act_grad<ACT>(y);
+            if constexpr (NORM) {
+                const float dxh = dy[k] * gamma[c];
+                s1 += dxh;
+                s2 += dxh * xh[k];
+            }
+        }
+    }
+    if constexpr (NORM) { s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C; }
+#pragma unroll
+    for (int k = 0; k < RN_PER; ++k) {
+        const int c = lane + 64 * k;
+        if (c < Cpad) {
+            float o = 0.0f;
+            if (ok && c < C) {
+                if constexpr (NORM) o = rstd * (dy[k] * gamma[c] - s1 - xh[k] * s2);
+                else o = dy[k];
+            }
+            dz[r * lddz + c] = o;
+        }
+        if constexpr (NORM) {
+            if (c < C) {
+                t_dy[r * C + c] = dy[k];
+                t_dyx[r * C + c] = dy[k] * xh[k];
+            }
+        }
+    }
+}
+
+// out[i, c] = sum_{s < S} m[i*S + s, c]   (then the overflow rows are added by slot_sum_ovf_kernel)
+__global__ __launch_bounds__(256) void slot_sum_kernel(const float* __restrict__ m, long long ldm, int C, int N, int S,
+                                                       float* __restrict__ out, long long ldo) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(t / C), c = (int)(t % C);
+    if (i >= N) return;
+    float s = 0.0f;
+    for (int k = 0; k < S; ++k) s += m[((long long)i * S + k) * ldm + c];
+    out[(long long)i * ldo + c] = s;
+}
+__global__ __launch_bounds__(256) void slot_sum_ovf_kernel(const float* __restrict__ m, long long ldm, int C, EdgeGraph g,
+                                                           int S, float* __restrict__ out, long long ldo) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int q = (int)(t / C), c = (int)(t % C);
+    if (!g.ovf_cnt || q >= *g.ovf_cnt) return;
+    out[(long long)g.ovf_centre[q] * ldo + c] += m[((long long)g.N * S + q) * ldm + c];    // <= 1 overflow row per centre
+}
+
+}  // namespace gn
+
+// =============================================================== launchers
+namespace gn {
+
+static inline unsigned gblocks(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+hipError_t launch_edge_rows(const EdgeGraph& g, int S, int* ic, int* jc, hipStream_t st) {
+    const long long rows = (long long)g.N * S + g.N;
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(edge_rows_kernel, dim3(gblocks(rows, 256)), dim3(256), 0, st, g, S, ic, jc, rows);
+    return hipGetLastError();
+}
+hipError_t launch_edge_gather_pre(const float* PQ, int H1p, const int* ic, const int* jc, long long rows, float* pre,
+                                  hipStream_t st) {
+    if (rows == 0) return hipSuccess;
+    if (H1p & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(edge_gather_pre_kernel, dim3(gblocks(rows * (H1p >> 2), 256)), dim3(256), 0, st, PQ, H1p, ic, jc,
+                       rows, pre);
+    return hipGetLastError();
+}
+hipError_t launch_rownorm_act_fwd(const float* z, long long ldz, int C, const int* valid, const float* gamma,
+                                  const float* beta, float eps, int act, float* a, long long lda, int Cpad, float* stats,
+                                  long long rows, hipStream_t st) {
+    if (rows == 0) return hipSuccess;
+    if (C < 1 || Cpad < C || Cpad > RN_MAXC || act < 0 || act > 1 || ((gamma != nullptr) != (beta != nullptr)))
+        return hipErrorInvalidValue;
+    const dim3 grid(gblocks(rows, 4)), block(256);
+    const bool norm = gamma != nullptr;
+#define GN_RN_FWD(NRM, ACT) hipLaunchKernelGGL((rownorm_act_fwd_kernel<NRM, ACT>), grid, block, 0, st, z, ldz, C, valid, gamma, beta, eps, a, lda, Cpad, stats, rows)
+    if (norm) { if (act == 0) GN_RN_FWD(true, 0); else GN_RN_FWD(true, 1); }
+    else { if (act == 0) GN_RN_FWD(false, 0); else GN_RN_FWD(false, 1); }
+#undef GN_RN_FWD
+    return hipGetLastError();
+}
+hipError_t launch_rownorm_act_bwd(const float* g, long long ldg, const int* gidx, const float* z, long long ldz, int C,
+                                  const int* valid, const float* gamma, const float* beta, const float* stats, int act,
+                                  float* dz, long long lddz, int Cpad, float* t_dy, float* t_dyx, long long rows,
+                                  hipStream_t st) {
+    if (rows == 0) return hipSuccess;
+    const bool norm = gamma != nullptr;
+    if (C < 1 || Cpad < C || Cpad > RN_MAXC || act < 0 || act > 1 || (norm && (!beta || !stats || !t_dy || !t_dyx)))
+        return hipErrorInvalidValue;
+    const dim3 grid(gblocks(rows, 4)), block(256);
+#define GN_RN_BWD(NRM, ACT) hipLaunchKernelGGL((rownorm_act_bwd_kernel<NRM, ACT>), grid, block, 0, st, g, ldg, gidx, z, ldz, C, valid, gamma, beta, stats, dz, lddz, Cpad, t_dy, t_dyx, rows)
+    if (norm) { if (act == 0) GN_RN_BWD(true, 0); else GN_RN_BWD(true, 1); }
+    else { if (act == 0) GN_RN_BWD(false, 0); else GN_RN_BWD(false, 1); }
+#undef GN_RN_BWD
+    return hipGetLastError();
+}
+hipError_t launch_slot_sum(const float* m, long long ldm, int C, const EdgeGraph& g, int S, float* out, long long ldo,
+                           hipStream_t st) {
+    if (g.N == 0) return hipSuccess;
+    hipLaunchKernelGGL(slot_sum_kernel, dim3(gblocks((long long)g.N * C, 256)), dim3(256), 0, st, m, ldm, C, g.N, S, out, ldo);
+    if (g.ovf_cnt)
+        hipLaunchKernelGGL(slot_sum_ovf_kernel, dim3(gblocks((long long)g.N * C, 256)), dim3(256), 0, st, m, ldm, C, g, S,
+                           out, ldo);
+    return hipGetLastError();
+}
+
+}  // namespace gn

@@ -47,6 +47,19 @@ hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p
                            long long ldg, void* saved, float* slab, float* db2_part, hipStream_t st);
 hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows,
                             const int* hubs, const int* nhubs, int N, void* dQ, long long ldq, hipStream_t st);
+// generic.hip
+hipError_t launch_edge_rows(const EdgeGraph& g, int S, int* ic, int* jc, hipStream_t st);
+hipError_t launch_edge_gather_pre(const float* PQ, int H1p, const int* ic, const int* jc, long long rows, float* pre,
+                                  hipStream_t st);
+hipError_t launch_rownorm_act_fwd(const float* z, long long ldz, int C, const int* valid, const float* gamma,
+                                  const float* beta, float eps, int act, float* a, long long lda, int Cpad, float* stats,
+                                  long long rows, hipStream_t st);
+hipError_t launch_rownorm_act_bwd(const float* g, long long ldg, const int* gidx, const float* z, long long ldz, int C,
+                                  const int* valid, const float* gamma, const float* beta, const float* stats, int act,
+                                  float* dz, long long lddz, int Cpad, float* t_dy, float* t_dyx, long long rows,
+                                  hipStream_t st);
+hipError_t launch_slot_sum(const float* m, long long ldm, int C, const EdgeGraph& g, int S, float* out, long long ldo,
+                           hipStream_t st);
 // pool.hip
 hipError_t launch_pack_weights(const long long* desc, int ndesc, hipStream_t st);
 hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr, int B, const int* codes, int ns,

@@ -335,6 +335,185 @@ class _DynEdgeFunction(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class _DynEdgeGenericFunction(torch.autograd.Function):
+    """Same contract as :class:`_DynEdgeFunction` for ``activation_layer="gelu"`` and / or
+    ``add_norm_layer=True`` (``dynedge.py:160-167,198-231``): the edge MLP runs unfused on edge-row tensors
+    (``csrc/generic.hip``), every Linear on the MFMA GEMM kernels, storage fp32.
+
+    ``params``: per conv layer ``W1, b1, [g1, be1], W2, b2, [g2, be2]``, per post layer ``W, b, [g, be]``
+    (LayerNorm weight / bias present iff ``cfg["norm"]``)."""
+
+    @staticmethod
+    def _split(cfg, params):
+        step = 4 if cfg["norm"] else 2
+        conv, off = [], 0
+        for _ in range(cfg["nconv"]):
+            conv.append((params[off: off + step], params[off + step: off + 2 * step]))
+            off += 2 * step
+        post = [params[off + step * t: off + step * (t + 1)] for t in range(cfg["npost"])]
+        return conv, post
+
+    @staticmethod
+    def forward(ctx, cfg: dict, x: Tensor, *params: Tensor) -> Tensor:  # type: ignore[override]
+        mode, act = cfg["mode"], cfg["act"]
+        dt, ku = ops.mode_dtype(mode), ops.gemm_kunit(mode)
+        batch, ptr, g = cfg["batch"], cfg["ptr"], cfg["graph"]
+        conv_p, post_p = _DynEdgeGenericFunction._split(cfg, params)
+        N, F = int(x.shape[0]), int(x.shape[1])
+        gv = cfg["globals"]
+        G = 0 if (gv is None or cfg["globals_after"]) else int(gv.shape[1])
+        F0 = F + G
+        x0 = ops.concat_globals(x, gv if G else None, batch, ops.round_up(F0, 32))
+        xs: List[Tuple[Tensor, int]] = [(x0, F0)]
+        graphs, saved, knn_coords = [], [], []
+        plan = None
+        nconv = cfg["nconv"]
+        for l, (p1, p2) in enumerate(conv_p):
+            W1, b1, W2, b2 = p1[0], p1[1], p2[0], p2[1]
+            ln1 = (p1[2], p1[3]) if cfg["norm"] else (None, None)
+            ln2 = (p2[2], p2[3]) if cfg["norm"] else (None, None)
+            xin, Fin = xs[-1]
+            H1, H2 = int(W1.shape[0]), int(W2.shape[0])
+            H1p, H2r = ops.round_up(H1, 32), ops.round_up(H2, 8)
+            Wa, Wb = W1[:, :Fin], W1[:, Fin:]
+            Wpq = torch.zeros((2 * H1p, Fin), dtype=torch.float32, device=x.device)
+            Wpq[:H1] = Wa - Wb
+            Wpq[H1p:H1p + H1] = Wb
+            bpq = torch.zeros(2 * H1p, dtype=torch.float32, device=x.device)
+            bpq[:H1] = b1
+            PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), ops.pack_weight(Wpq, [Fin], dt, ku), 2 * H1p, bias=bpq)
+            ic, jc = ops.edge_rows(g)
+            pre1 = ops.edge_gather_pre(PQ, H1p, ic, jc)
+            a1, st1 = ops.rownorm_act_fwd(pre1, H1, act, ln1[0], ln1[1], valid=jc, cpad=H1p)
+            z2 = ops.linear_fwd(mode, [(a1, H1p)], ops.pack_weight(W2, [H1], dt, ku), H2, bias=b2.contiguous(),
+                                out_cols=H2r)
+            m, st2 = ops.rownorm_act_fwd(z2, H2, act, ln2[0], ln2[1], valid=jc, cpad=H2r)
+            out = ops.slot_sum(m, H2, g)
+            graphs.append(g)
+            saved.append((pre1, a1, st1, z2, st2))
+            xs.append((out, H2))
+            if l + 1 < nconv:
+                cols = _subset_cols(cfg["features_subset"], H2)
+                if plan is None:
+                    plan = ops.knn_plan(ptr, N)
+                g = ops.knn_graph(out, cols, batch, ptr, cfg["k"], strict=cfg["strict"], plan=plan)
+                knn_coords.append(out[:, cols])
+        zs, sts = [], []
+        segs = xs
+        for (pp) in post_p:
+            W, b = pp[0], pp[1]
+            gam, bet = (pp[2], pp[3]) if cfg["norm"] else (None, None)
+            P_ = int(W.shape[0])
+            z = ops.linear_fwd(mode, _ksegs(segs), ops.pack_weight(W, [w for _, w in segs], dt, ku), P_,
+                               bias=b.contiguous(), out_cols=ops.round_up(P_, 8))
+            y, st = ops.rownorm_act_fwd(z, P_, act, gam, bet, cpad=ops.round_up(P_, 8))
+            zs.append(z); sts.append(st)
+            segs = [(y, P_)]
+        y_last, P = segs[0]
+        ctx.cfg, ctx.xs, ctx.graphs, ctx.saved, ctx.zs, ctx.sts, ctx.params = cfg, xs, graphs, saved, zs, sts, params
+        ctx.amin = ctx.amax = None
+        cfg["trace"] = ({"conv_out": [t for t, _ in xs], "graphs": graphs, "post": y_last[:, :P],
+                         "knn_coords": knn_coords} if cfg.get("want_trace") else None)
+        if cfg["pools"]:
+            pooled, ctx.amin, ctx.amax = ops.segment_pool_fwd(y_last, P, ptr, cfg["pools"])
+            return pooled
+        return y_last[:, :P] if int(y_last.shape[1]) != P else y_last
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):  # type: ignore[override]
+        cfg = ctx.cfg
+        mode, act = cfg["mode"], cfg["act"]
+        dt, ku = ops.mode_dtype(mode), ops.gemm_kunit(mode)
+        batch, ptr = cfg["batch"], cfg["ptr"]
+        params = ctx.params
+        conv_p, post_p = _DynEdgeGenericFunction._split(cfg, params)
+        step = 4 if cfg["norm"] else 2
+        nconv, npost = cfg["nconv"], cfg["npost"]
+        xs = ctx.xs
+        N, dev = int(xs[0][0].shape[0]), xs[0][0].device
+        grads: List[Optional[Tensor]] = [None] * len(params)
+        post_base = 2 * step * nconv
+        P = int(post_p[-1][0].shape[0])
+        gout = gout.contiguous().to(torch.float32)
+        if cfg["pools"]:
+            gy = ops.segment_pool_bwd(gout, P, ptr, batch, N, cfg["pools"], ctx.amin, ctx.amax, None)
+        else:
+            gy = torch.zeros((N, ops.round_up(P, 8)), dtype=torch.float32, device=dev)
+            gy[:, :P] = gout
+
+        seg_pad = [ops.round_up(w, 32) for _, w in xs]
+        seg_off = [sum(seg_pad[:i]) for i in range(len(xs))]
+        dXcat = None
+        for t in reversed(range(npost)):
+            pp = post_p[t]
+            W = pp[0]
+            gam, bet = (pp[2], pp[3]) if cfg["norm"] else (None, None)
+            Pt = int(W.shape[0])
+            dz, dgam, dbet = ops.rownorm_act_bwd(gy, ctx.zs[t], Pt, act, gam, bet, ctx.sts[t], cpad=ops.round_up(Pt, 8))
+            in_segs = xs if t == 0 else [(None, int(post_p[t - 1][0].shape[0]))]
+            if t > 0:   # input of layer t = activation output of layer t-1: recompute it from the saved z
+                pq = post_p[t - 1]
+                gq, bq = (pq[2], pq[3]) if cfg["norm"] else (None, None)
+                Pprev = int(pq[0].shape[0])
+                yprev, _ = ops.rownorm_act_fwd(ctx.zs[t - 1], Pprev, act, gq, bq, cpad=ops.round_up(Pprev, 8))
+                in_segs = [(yprev, Pprev)]
+            dWt, dbt = ops.linear_wgrad(mode, dz, Pt, _ksegs(in_segs), with_bias=True)
+            base = post_base + step * t
+            grads[base] = _unpad_cols(dWt, [w for _, w in in_segs], 4)
+            grads[base + 1] = dbt
+            if cfg["norm"]:
+                grads[base + 2], grads[base + 3] = dgam, dbet
+            if t > 0:
+                gy = ops.linear_fwd(mode, _ksegs([(dz, Pt)]), ops.pack_weight(W.t(), [Pt], dt, ku), Pprev,
+                                    out_cols=ops.round_up(Pprev, 8))
+            else:
+                WT = torch.zeros((sum(seg_pad), Pt), dtype=torch.float32, device=dev)
+                off = 0
+                for s_, (_, w) in enumerate(xs):
+                    WT[seg_off[s_]: seg_off[s_] + w] = W[:, off: off + w].t()
+                    off += w
+                dXcat = ops.linear_fwd(mode, _ksegs([(dz, Pt)]), ops.pack_weight(WT, [Pt], dt, ku), sum(seg_pad))
+
+        for l in reversed(range(nconv)):
+            p1, p2 = conv_p[l]
+            W1, W2 = p1[0], p2[0]
+            ln1 = (p1[2], p1[3]) if cfg["norm"] else (None, None)
+            ln2 = (p2[2], p2[3]) if cfg["norm"] else (None, None)
+            xin, Fin = xs[l]
+            H1, H2 = int(W1.shape[0]), int(W2.shape[0])
+            H1p, H2r = ops.round_up(H1, 32), ops.round_up(H2, 8)
+            g = ctx.graphs[l]
+            pre1, a1, st1, z2, st2 = ctx.saved[l]
+            ic, jc = ops.edge_rows(g)
+            g_out = dXcat[:, seg_off[l + 1]: seg_off[l + 1] + H2]
+            dz2, dg2, db2n = ops.rownorm_act_bwd(g_out, z2, H2, act, ln2[0], ln2[1], st2, valid=jc, gidx=ic, cpad=H2r)
+            dW2, db2 = ops.linear_wgrad(mode, dz2, H2, [(a1, H1p)], with_bias=True)
+            da1 = ops.linear_fwd(mode, _ksegs([(dz2, H2)]), ops.pack_weight(W2.t(), [H2], dt, ku), H1, out_cols=H1p)
+            dpre1, dg1, db1n = ops.rownorm_act_bwd(da1, pre1, H1, act, ln1[0], ln1[1], st1, valid=jc, cpad=H1p)
+            dPQ = torch.empty((N, 2 * H1p), dtype=torch.float32, device=dev)
+            dPQ[:, :H1p] = ops.slot_sum(dpre1, H1p, g)
+            ops.edgeconv_dq_gather(ops.MODE_F32, g, dpre1, H1p, dPQ[:, H1p:])
+            dWpq, dbpq = ops.linear_wgrad(mode, dPQ, 2 * H1p, _ksegs([(xin, Fin)]), with_bias=True)
+            dWpq = dWpq[:, :Fin]
+            dWp, dWq = dWpq[:H1], dWpq[H1p:H1p + H1]
+            base = 2 * step * l
+            grads[base] = torch.cat([dWp, dWq - dWp], dim=1)
+            grads[base + 1] = dbpq[:H1]
+            grads[base + step] = dW2[:, :H1]
+            grads[base + step + 1] = db2
+            if cfg["norm"]:
+                grads[base + 2], grads[base + 3] = dg1, db1n
+                grads[base + step + 2], grads[base + step + 3] = dg2, db2n
+            if l > 0:
+                Wa, Wb = W1[:, :Fin], W1[:, Fin:]
+                WpqT = torch.zeros((Fin, 2 * H1p), dtype=torch.float32, device=dev)
+                WpqT[:, :H1] = (Wa - Wb).t()
+                WpqT[:, H1p:H1p + H1] = Wb.t()
+                ops.linear_fwd(mode, [(dPQ, 2 * H1p)], ops.pack_weight(WpqT, [2 * H1p], dt, ku), Fin,
+                               out=dXcat[:, seg_off[l]: seg_off[l] + Fin], accum=True)
+        return (None, None) + tuple(grads)
+
+
 class DynEdge(GNN):
     """DynEdge (dynamical edge convolutional) model on hand-written gfx950 kernels.
 
@@ -476,11 +655,13 @@ class DynEdge(GNN):
             self._graph_columns = list(graph_columns)
         return self
 
+    def _is_generic(self) -> bool:
+        """GELU and / or LayerNorm: the unfused kernels of csrc/generic.hip (the fused path is relu, no norm)."""
+        return not isinstance(self._activation, torch.nn.ReLU) or self._add_norm_layer
+
     def _check_supported(self) -> None:
-        if not isinstance(self._activation, torch.nn.ReLU) or self._add_norm_layer:
-            raise NotImplementedError(
-                "graphnet_amd.DynEdge: the HIP path implements activation_layer='relu' without norm layers "
-                "(the reference default); GELU / LayerNorm epilogues are not built yet and there is no fallback.")
+        if not isinstance(self._activation, (torch.nn.ReLU, torch.nn.GELU)):
+            raise NotImplementedError("graphnet_amd.DynEdge: activation must be relu or gelu (no fallback)")
         if any(len(s) != 2 for s in self._dynedge_layer_sizes):
             raise NotImplementedError("graphnet_amd.DynEdge: each DynEdgeConv MLP must have exactly two layers.")
 
@@ -518,6 +699,15 @@ class DynEdge(GNN):
             self.__dict__["_wbuf"] = wb          # plain attribute: not a module / parameter / buffer
         return wb
 
+    def _generic_params(self) -> List[Tensor]:
+        """Linear (and LayerNorm) parameters in module order: conv MLPs, then the post-processing MLP."""
+        ps: List[Tensor] = []
+        for seq in [conv.nn for conv in self._conv_layers] + [self._post_processing]:
+            for m in seq:
+                if isinstance(m, (torch.nn.Linear, torch.nn.LayerNorm)):
+                    ps += [m.weight, m.bias]
+        return ps
+
     def _kernel_params(self) -> List[Tensor]:
         ps: List[Tensor] = []
         for conv in self._conv_layers:
@@ -547,7 +737,12 @@ class DynEdge(GNN):
             "pools": None if self._skip_readout else self._global_pooling_schemes,
             "want_trace": return_trace, "wbuf": self._weight_buffers(),
         }
-        out = _DynEdgeFunction.apply(cfg, x, *self._kernel_params())
+        if self._is_generic():
+            cfg["act"] = "gelu" if isinstance(self._activation, torch.nn.GELU) else "relu"
+            cfg["norm"] = bool(self._add_norm_layer)
+            out = _DynEdgeGenericFunction.apply(cfg, x, *self._generic_params())
+        else:
+            out = _DynEdgeFunction.apply(cfg, x, *self._kernel_params())
         if not self._skip_readout:
             if self._global_pooling_schemes and self._add_global_variables_after_pooling:
                 out = torch.cat([out, gv], dim=1)

@@ -442,6 +442,77 @@ def edgeconv_dq_gather(mode: int, g: NeighbourTable, dpre: Tensor, H1p: int, dQ:
                                                     _rows(dQ, "dQ"), _st()))
 
 
+# ------------------------------------------------------------------------------ unfused variant blocks
+ACT_CODES = {"relu": 0, "gelu": 1}
+
+
+def edge_rows(g: NeighbourTable) -> Tuple[Tensor, Tensor]:
+    """(ic, jc): centre / source of every edge row of ``g`` (jc = -1 for empty slots); cached on the table."""
+    cached = getattr(g, "_rows_cache", None)
+    if cached is not None:
+        return cached
+    dev = g.nbr.device
+    ic = torch.empty(g.rows, dtype=torch.int32, device=dev)
+    jc = torch.empty(g.rows, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().gn_edge_rows(*g.c_args(), _p(ic), _p(jc), _st()))
+    g._rows_cache = (ic, jc)
+    return ic, jc
+
+
+def edge_gather_pre(PQ: Tensor, H1p: int, ic: Tensor, jc: Tensor) -> Tensor:
+    _need(PQ, torch.float32, "PQ")
+    R = int(ic.shape[0])
+    pre = torch.empty((R, H1p), dtype=torch.float32, device=PQ.device)
+    with _timed("generic_edge"):
+        _lib.check(_lib.lib().gn_edge_gather_pre(_p(PQ), H1p, _p(ic), _p(jc), R, _p(pre), _st()))
+    return pre
+
+
+def rownorm_act_fwd(z: Tensor, C: int, act: str, gamma: Optional[Tensor] = None, beta: Optional[Tensor] = None,
+                    valid: Optional[Tensor] = None, cpad: Optional[int] = None, eps: float = 1e-5):
+    """``act(LayerNorm(z[:, :C]))`` (LayerNorm only with gamma/beta) -> (a [R, cpad] fp32, stats [R, 2] | None)."""
+    _need(z, torch.float32, "z")
+    R = int(z.shape[0])
+    cpad = C if cpad is None else cpad
+    a = torch.empty((R, cpad), dtype=torch.float32, device=z.device)
+    stats = torch.empty((R, 2), dtype=torch.float32, device=z.device) if gamma is not None else None
+    with _timed("generic_rows"):
+        _lib.check(_lib.lib().gn_rownorm_act_fwd(_p(z), _rows(z, "z"), C, _p(valid), _p(gamma), _p(beta), float(eps),
+                                                 ACT_CODES[act], _p(a), cpad, cpad, _p(stats), R, _st()))
+    return a, stats
+
+
+def rownorm_act_bwd(g: Tensor, z: Tensor, C: int, act: str, gamma: Optional[Tensor] = None, beta: Optional[Tensor] = None,
+                    stats: Optional[Tensor] = None, valid: Optional[Tensor] = None, gidx: Optional[Tensor] = None,
+                    cpad: Optional[int] = None):
+    """Backward of :func:`rownorm_act_fwd` -> (dz [R, cpad], dgamma | None, dbeta | None)."""
+    _need(g, torch.float32, "g"); _need(z, torch.float32, "z")
+    R = int(z.shape[0])
+    cpad = C if cpad is None else cpad
+    dz = torch.empty((R, cpad), dtype=torch.float32, device=z.device)
+    t1 = t2 = None
+    if gamma is not None:
+        if C % 4:
+            raise NotImplementedError("LayerNorm widths must be multiples of 4 on the HIP path")
+        t1 = torch.empty((R, C), dtype=torch.float32, device=z.device)
+        t2 = torch.empty((R, C), dtype=torch.float32, device=z.device)
+    with _timed("generic_rows"):
+        _lib.check(_lib.lib().gn_rownorm_act_bwd(_p(g), _rows(g, "g"), _p(gidx), _p(z), _rows(z, "z"), C, _p(valid),
+                                                 _p(gamma), _p(beta), _p(stats), ACT_CODES[act], _p(dz), cpad, cpad,
+                                                 _p(t1), _p(t2), R, _st()))
+    if gamma is None:
+        return dz, None, None
+    return dz, colsum(t2, C), colsum(t1, C)
+
+
+def slot_sum(m: Tensor, C: int, g: NeighbourTable) -> Tensor:
+    _need(m, torch.float32, "m")
+    out = torch.empty((g.N, C), dtype=torch.float32, device=m.device)
+    with _timed("generic_edge"):
+        _lib.check(_lib.lib().gn_slot_sum(_p(m), _rows(m, "m"), C, *g.c_args(), _p(out), C, _st()))
+    return out
+
+
 # ------------------------------------------------------------------------------ pooling
 def _codes(schemes: Sequence[str]):
     return (ctypes.c_int32 * len(schemes))(*[POOL_CODES[s] for s in schemes])

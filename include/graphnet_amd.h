@@ -154,6 +154,32 @@ int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int
                           const int32_t* rev_rows, const int32_t* hubs, const int32_t* nhubs, int32_t N,
                           void* dQ, int64_t ldq, void* stream);
 
+/* ---- unfused edge-MLP building blocks: DynEdge(activation_layer="gelu" / add_norm_layer=True) ----------
+ * (dynedge.py:160-167,198-231: GELU and LayerNorm after every Linear of the edge and post MLPs.)  The fused
+ * kernels above keep one relu bit per activation; GELU / LayerNorm need the pre-activations and a reduction
+ * over the whole row, so these variants run on edge-row tensors [N*S + N, .] in HBM, fp32. */
+/* ic[r], jc[r] = centre / source of edge row r (jc = -1: empty slot), r < N*S + N */
+int gn_edge_rows(const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src, const int32_t* ovf_cnt,
+                 int32_t N, int32_t K, int32_t* ic, int32_t* jc, void* stream);
+/* pre[r, :H1p] = P[ic[r]] + Q[jc[r]] (PQ fp32 [N, 2*H1p]), 0 for empty slots */
+int gn_edge_gather_pre(const float* PQ, int32_t H1p, const int32_t* ic, const int32_t* jc, int64_t rows,
+                       float* pre, void* stream);
+/* a[r, c] = act(gamma ? LayerNorm(z[r, :C]) : z[r, c]); 0 for C <= c < Cpad and for rows with valid[r] < 0;
+ * act: 0 relu, 1 gelu (erf); stats[r] = (mean, rstd) when gamma != NULL; Cpad <= 512. */
+int gn_rownorm_act_fwd(const float* z, int64_t ldz, int32_t C, const int32_t* valid, const float* gamma,
+                       const float* beta, float eps, int32_t act, float* a, int64_t lda, int32_t Cpad,
+                       float* stats, int64_t rows, void* stream);
+/* dz = d(loss)/dz given g = d(loss)/da (row gidx ? gidx[r] : r of g); with LayerNorm also the per-row terms
+ * t_dy[rows, C], t_dyx[rows, C] whose column sums are dbeta and dgamma (gn_colsum). */
+int gn_rownorm_act_bwd(const float* g, int64_t ldg, const int32_t* gidx, const float* z, int64_t ldz, int32_t C,
+                       const int32_t* valid, const float* gamma, const float* beta, const float* stats,
+                       int32_t act, float* dz, int64_t lddz, int32_t Cpad, float* t_dy, float* t_dyx,
+                       int64_t rows, void* stream);
+/* out[i, :C] = sum over the slots (and the overflow row) of centre i of m[row, :C] */
+int gn_slot_sum(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, const int32_t* ovf_centre,
+                const int32_t* ovf_src, const int32_t* ovf_cnt, int32_t N, int32_t K, float* out, int64_t ldo,
+                void* stream);
+
 /* ---- operand copies of the weights ------------------------------------------------------- */
 /* One launch rewrites every padded / transposed / bf16 copy of the weights the kernels above consume
  * (what torch.nn.Linear does implicitly with its own weight).  desc: DEVICE int64[ndesc][10] =

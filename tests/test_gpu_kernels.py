@@ -428,6 +428,39 @@ def test_single_layer_model_forward_backward(oracle, name, mode, tol):
             assert norm_err(p.grad, po.grad) < 5e-2, f"{name}: grad {kn}"
 
 
+@pytest.mark.parametrize("act,norm", [("gelu", False), (None, True), ("gelu", True)])
+@pytest.mark.parametrize("name,mode,tol", MODES)
+def test_gelu_layernorm_variants(oracle, name, mode, tol, act, norm):
+    """DynEdge(activation_layer="gelu", add_norm_layer=True) (dynedge.py:160-167,198-231) on the unfused
+    kernels of csrc/generic.hip: two DynEdgeConv layers (teacher-forced on the graphs the device built),
+    post MLP, pooling, read-out; output and every gradient (incl. LayerNorm weight / bias) vs the oracle."""
+    import graphnet_amd as g
+    b = _batch(7, seed=31)
+    b.x[3:16, :3] = b.x[2, :3]
+    kw = dict(dynedge_layer_sizes=[(64, 128), (96, 128)], post_processing_layer_sizes=[96, 64], readout_layer_sizes=[32],
+              global_pooling_schemes=["min", "max", "mean", "sum"], activation_layer=act, add_norm_layer=norm)
+    torch.manual_seed(5)
+    ref = oracle.DynEdgeOracle(7, **kw)
+    m = g.DynEdge(7, **kw)
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).set_backend(dtype=name)
+    y, trace = m(b.to(DEV), return_trace=True)
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
+    (y * w.to(DEV)).sum().backward()
+    bc = b.to("cpu")
+    forced = [t.edge_index().cpu() for t in trace["graphs"]]
+    assert torch.equal(forced[0], oracle.knn_graph(bc.x, 8, bc.batch, [0, 1, 2]))
+    yo = ref(bc.x, forced[0], bc.batch, bc.n_pulses, forced_edges=forced)
+    (yo * w).sum().backward()
+    assert rel_err(y, yo.detach()) < tol
+    for (kn, p), (_, po) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, kn
+        if mode == 0:
+            assert rel_err(p.grad, po.grad) < 2e-3, f"{name}: grad {kn}"
+        else:
+            assert norm_err(p.grad, po.grad) < 5e-2, f"{name}: grad {kn}"
+
+
 # ------------------------------------------------------------------------------ pooling
 def test_segment_pool_forward_backward(oracle):
     from graphnet_amd import ops

@@ -172,7 +172,7 @@ def test_unsupported_configuration_fails_loudly():
     import graphnet_amd as g
     from graphnet_amd.synthetic import synthetic_icecube86_batch
     b = synthetic_icecube86_batch(2, seed=1)
-    m = g.DynEdge(7, activation_layer="gelu").to(DEV)
+    m = g.DynEdge(7, dynedge_layer_sizes=[(64, 128, 96)]).to(DEV)     # three-layer edge MLP: no kernel for it
     with pytest.raises(NotImplementedError):
         m(b.to(DEV))
     with pytest.raises(RuntimeError):
