@@ -204,7 +204,7 @@ int gn_rownorm_act_fwd(const float* z, int64_t ldz, int32_t C, const int32_t* va
                        float eps, int32_t act, float* a, int64_t lda, int32_t Cpad, float* stats, int64_t rows,
                        void* stream) {
     hipError_t r = gn::launch_rownorm_act_fwd(z, ldz, C, valid, gamma, beta, eps, act, a, lda, Cpad, stats, rows, S(stream));
-    if (r == hipErrorInvalidValue) return bad("gn_rownorm_act_fwd", "need 1 <= C <= Cpad <= 512, act in {0,1}, gamma and beta together");
+    if (r == hipErrorInvalidValue) return bad("gn_rownorm_act_fwd", "need 1 <= C <= Cpad <= 512, act in 0..3, gamma and beta together");
     return fail(r, "gn_rownorm_act_fwd");
 }
 int gn_rownorm_act_bwd(const float* g, int64_t ldg, const int32_t* gidx, const float* z, int64_t ldz, int32_t C,
@@ -212,7 +212,7 @@ int gn_rownorm_act_bwd(const float* g, int64_t ldg, const int32_t* gidx, const f
                        float* dz, int64_t lddz, int32_t Cpad, float* t_dy, float* t_dyx, int64_t rows, void* stream) {
     hipError_t r = gn::launch_rownorm_act_bwd(g, ldg, gidx, z, ldz, C, valid, gamma, beta, stats, act, dz, lddz, Cpad, t_dy,
                                               t_dyx, rows, S(stream));
-    if (r == hipErrorInvalidValue) return bad("gn_rownorm_act_bwd", "need 1 <= C <= Cpad <= 512, act in {0,1}; LayerNorm needs beta, stats, t_dy, t_dyx");
+    if (r == hipErrorInvalidValue) return bad("gn_rownorm_act_bwd", "need 1 <= C <= Cpad <= 512, act in 0..3; LayerNorm needs beta, stats, t_dy, t_dyx");
     return fail(r, "gn_rownorm_act_bwd");
 }
 int gn_slot_sum(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, const int32_t* ovf_centre,

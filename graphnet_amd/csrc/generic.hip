@@ -54,14 +54,20 @@ __global__ __launch_bounds__(256) void edge_gather_pre_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------- activations
-// ACT: 0 = relu, 1 = gelu (erf form, torch.nn.GELU() default)
+// ACT: 0 = relu, 1 = gelu (erf form, torch.nn.GELU() default), 2 = leaky relu (slope 0.01, torch default),
+//      3 = identity
 template <int ACT> __device__ __forceinline__ float act_fwd(float y) {
     if constexpr (ACT == 0) return fmaxf(y, 0.0f);
-    else return 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+    else if constexpr (ACT == 1) return 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+    else if constexpr (ACT == 2) return y > 0.0f ? y : 0.01f * y;
+    else return y;
 }
 template <int ACT> __device__ __forceinline__ float act_grad(float y) {
     if constexpr (ACT == 0) return y > 0.0f ? 1.0f : 0.0f;
-    else return 0.5f * (1.0f + erff(y * 0.70710678118654752440f)) + y * 0.39894228040143267794f * expf(-0.5f * y * y);
+    else if constexpr (ACT == 1)
+        return 0.5f * (1.0f + erff(y * 0.70710678118654752440f)) + y * 0.39894228040143267794f * expf(-0.5f * y * y);
+    else if constexpr (ACT == 2) return y > 0.0f ? 1.0f : 0.01f;
+    else return 1.0f;
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -220,13 +226,13 @@ hipError_t launch_rownorm_act_fwd(const float* z, long long ldz, int C, const in
                                   const float* beta, float eps, int act, float* a, long long lda, int Cpad, float* stats,
                                   long long rows, hipStream_t st) {
     if (rows == 0) return hipSuccess;
-    if (C < 1 || Cpad < C || Cpad > RN_MAXC || act < 0 || act > 1 || ((gamma != nullptr) != (beta != nullptr)))
+    if (C < 1 || Cpad < C || Cpad > RN_MAXC || act < 0 || act > 3 || ((gamma != nullptr) != (beta != nullptr)))
         return hipErrorInvalidValue;
     const dim3 grid(gblocks(rows, 4)), block(256);
     const bool norm = gamma != nullptr;
 #define GN_RN_FWD(NRM, ACT) hipLaunchKernelGGL((rownorm_act_fwd_kernel<NRM, ACT>), grid, block, 0, st, z, ldz, C, valid, gamma, beta, eps, a, lda, Cpad, stats, rows)
-    if (norm) { if (act == 0) GN_RN_FWD(true, 0); else GN_RN_FWD(true, 1); }
-    else { if (act == 0) GN_RN_FWD(false, 0); else GN_RN_FWD(false, 1); }
+    if (norm) { if (act == 0) GN_RN_FWD(true, 0); else if (act == 1) GN_RN_FWD(true, 1); else if (act == 2) GN_RN_FWD(true, 2); else GN_RN_FWD(true, 3); }
+    else { if (act == 0) GN_RN_FWD(false, 0); else if (act == 1) GN_RN_FWD(false, 1); else if (act == 2) GN_RN_FWD(false, 2); else GN_RN_FWD(false, 3); }
 #undef GN_RN_FWD
     return hipGetLastError();
 }
@@ -236,12 +242,12 @@ hipError_t launch_rownorm_act_bwd(const float* g, long long ldg, const int* gidx
                                   hipStream_t st) {
     if (rows == 0) return hipSuccess;
     const bool norm = gamma != nullptr;
-    if (C < 1 || Cpad < C || Cpad > RN_MAXC || act < 0 || act > 1 || (norm && (!beta || !stats || !t_dy || !t_dyx)))
+    if (C < 1 || Cpad < C || Cpad > RN_MAXC || act < 0 || act > 3 || (norm && (!beta || !stats || !t_dy || !t_dyx)))
         return hipErrorInvalidValue;
     const dim3 grid(gblocks(rows, 4)), block(256);
 #define GN_RN_BWD(NRM, ACT) hipLaunchKernelGGL((rownorm_act_bwd_kernel<NRM, ACT>), grid, block, 0, st, g, ldg, gidx, z, ldz, C, valid, gamma, beta, stats, dz, lddz, Cpad, t_dy, t_dyx, rows)
-    if (norm) { if (act == 0) GN_RN_BWD(true, 0); else GN_RN_BWD(true, 1); }
-    else { if (act == 0) GN_RN_BWD(false, 0); else GN_RN_BWD(false, 1); }
+    if (norm) { if (act == 0) GN_RN_BWD(true, 0); else if (act == 1) GN_RN_BWD(true, 1); else if (act == 2) GN_RN_BWD(true, 2); else GN_RN_BWD(true, 3); }
+    else { if (act == 0) GN_RN_BWD(false, 0); else if (act == 1) GN_RN_BWD(false, 1); else if (act == 2) GN_RN_BWD(false, 2); else GN_RN_BWD(false, 3); }
 #undef GN_RN_BWD
     return hipGetLastError();
 }

@@ -400,13 +400,14 @@ class _DynEdgeGenericFunction(torch.autograd.Function):
                 knn_coords.append(out[:, cols])
         zs, sts = [], []
         segs = xs
-        for (pp) in post_p:
+        post_acts = cfg.get("post_acts") or [act] * cfg["npost"]
+        for t, (pp) in enumerate(post_p):
             W, b = pp[0], pp[1]
             gam, bet = (pp[2], pp[3]) if cfg["norm"] else (None, None)
             P_ = int(W.shape[0])
             z = ops.linear_fwd(mode, _ksegs(segs), ops.pack_weight(W, [w for _, w in segs], dt, ku), P_,
                                bias=b.contiguous(), out_cols=ops.round_up(P_, 8))
-            y, st = ops.rownorm_act_fwd(z, P_, act, gam, bet, cpad=ops.round_up(P_, 8))
+            y, st = ops.rownorm_act_fwd(z, P_, post_acts[t], gam, bet, cpad=ops.round_up(P_, 8))
             zs.append(z); sts.append(st)
             segs = [(y, P_)]
         y_last, P = segs[0]
@@ -441,6 +442,7 @@ class _DynEdgeGenericFunction(torch.autograd.Function):
             gy = torch.zeros((N, ops.round_up(P, 8)), dtype=torch.float32, device=dev)
             gy[:, :P] = gout
 
+        post_acts = cfg.get("post_acts") or [act] * npost
         seg_pad = [ops.round_up(w, 32) for _, w in xs]
         seg_off = [sum(seg_pad[:i]) for i in range(len(xs))]
         dXcat = None
@@ -449,13 +451,14 @@ class _DynEdgeGenericFunction(torch.autograd.Function):
             W = pp[0]
             gam, bet = (pp[2], pp[3]) if cfg["norm"] else (None, None)
             Pt = int(W.shape[0])
-            dz, dgam, dbet = ops.rownorm_act_bwd(gy, ctx.zs[t], Pt, act, gam, bet, ctx.sts[t], cpad=ops.round_up(Pt, 8))
+            dz, dgam, dbet = ops.rownorm_act_bwd(gy, ctx.zs[t], Pt, post_acts[t], gam, bet, ctx.sts[t],
+                                                 cpad=ops.round_up(Pt, 8))
             in_segs = xs if t == 0 else [(None, int(post_p[t - 1][0].shape[0]))]
             if t > 0:   # input of layer t = activation output of layer t-1: recompute it from the saved z
                 pq = post_p[t - 1]
                 gq, bq = (pq[2], pq[3]) if cfg["norm"] else (None, None)
                 Pprev = int(pq[0].shape[0])
-                yprev, _ = ops.rownorm_act_fwd(ctx.zs[t - 1], Pprev, act, gq, bq, cpad=ops.round_up(Pprev, 8))
+                yprev, _ = ops.rownorm_act_fwd(ctx.zs[t - 1], Pprev, post_acts[t - 1], gq, bq, cpad=ops.round_up(Pprev, 8))
                 in_segs = [(yprev, Pprev)]
             dWt, dbt = ops.linear_wgrad(mode, dz, Pt, _ksegs(in_segs), with_bias=True)
             base = post_base + step * t
@@ -747,6 +750,71 @@ class DynEdge(GNN):
             if self._global_pooling_schemes and self._add_global_variables_after_pooling:
                 out = torch.cat([out, gv], dim=1)
             out = self._readout(out)
+        if return_trace:
+            trace = cfg["trace"] or {}
+            trace["global_variables"] = gv
+            return out, trace
+        return out
+
+
+class DynEdgeJINST(GNN):
+    """``DynEdgeJINST`` (``models/gnn/dynedge_jinst.py:16-161``, the architecture of arXiv:2209.03042) on the same
+    kernels: four DynEdgeConv layers with LeakyReLU edge MLPs (unfused kernels of ``csrc/generic.hip``: a leaky
+    relu is not one bit), skip-cat, nn1 + LeakyReLU, nn2, max / min / sum / mean pooling, homophily and pulse
+    count appended, LeakyReLU, nn3, LeakyReLU.  Same attribute names as the reference => same state-dict keys."""
+
+    def __init__(self, nb_inputs: int, layer_size_scale: int = 4):
+        c = layer_size_scale
+        l1, l2, l3, l4, l5, l6 = nb_inputs, c * 16 * 2, c * 32 * 2, c * 42 * 2, c * 32 * 2, c * 16 * 2
+        super().__init__(nb_inputs, l6)
+
+        def mlp(a: int, b: int, cc: int) -> torch.nn.Sequential:
+            return torch.nn.Sequential(torch.nn.Linear(a * 2, b), torch.nn.LeakyReLU(), torch.nn.Linear(b, cc),
+                                       torch.nn.LeakyReLU())
+        self.conv_add1 = _ConvParams(mlp(l1, l2, l3), 8, slice(0, 3))
+        self.conv_add2 = _ConvParams(mlp(l3, l4, l3), 8, slice(0, 3))
+        self.conv_add3 = _ConvParams(mlp(l3, l4, l3), 8, slice(0, 3))
+        self.conv_add4 = _ConvParams(mlp(l3, l4, l3), 8, slice(0, 3))
+        self.nn1 = torch.nn.Linear(l3 * 4 + l1, l4)
+        self.nn2 = torch.nn.Linear(l4, l5)
+        self.nn3 = torch.nn.Linear(4 * l5 + 5, l6)
+        self.lrelu = torch.nn.LeakyReLU()
+        self._compute_mode = ops.MODE_BF16
+        self._knn_strict = False
+
+    def set_backend(self, dtype: Optional[str] = None, knn_mode: Optional[str] = None) -> "DynEdgeJINST":
+        if dtype is not None:
+            self._compute_mode = {"fp32": ops.MODE_F32, "bf16": ops.MODE_BF16}[dtype]
+        if knn_mode is not None:
+            self._knn_strict = {"compat": False, "strict": True}[knn_mode]
+        return self
+
+    def forward(self, data: Any, return_trace: bool = False) -> Tensor:
+        x = data.x
+        if not x.is_cuda:
+            raise RuntimeError("graphnet_amd.DynEdgeJINST runs on an MI355X (HIP) device only; move the batch to 'cuda'.")
+        x = x.to(torch.float32)
+        ptr32, batch32, n_pulses = DynEdge._csr(self, data, x)
+        ei = _maybe(data, "edge_index")
+        g0 = (ops.table_from_edge_index(ei, int(x.shape[0]), 8) if ei is not None
+              else ops.knn_graph(x, [0, 1, 2], batch32, ptr32, 8, strict=self._knn_strict))
+        gv = ops.graph_globals(x, ptr32, g0, n_pulses)          # [mean_F | h_x h_y h_z h_t | log10 n]
+        F = int(x.shape[1])
+        cfg = {
+            "mode": self._compute_mode, "batch": batch32, "ptr": ptr32, "graph": g0, "nconv": 4, "npost": 2,
+            "globals": None, "globals_after": True, "features_subset": slice(0, 3), "k": 8,
+            "strict": self._knn_strict, "pools": ["max", "min", "sum", "mean"], "want_trace": return_trace,
+            "act": "leaky_relu", "post_acts": ["leaky_relu", "identity"], "norm": False,
+        }
+        params: List[Tensor] = []
+        for conv in (self.conv_add1, self.conv_add2, self.conv_add3, self.conv_add4):
+            params += [conv.nn[0].weight, conv.nn[0].bias, conv.nn[2].weight, conv.nn[2].bias]
+        params += [self.nn1.weight, self.nn1.bias, self.nn2.weight, self.nn2.bias]
+        pooled = _DynEdgeGenericFunction.apply(cfg, x, *params)
+        h = gv[:, F: F + 4]
+        feats = torch.cat([pooled, h[:, 3:4], h[:, 0:1], h[:, 1:2], h[:, 2:3],
+                           n_pulses.reshape(-1, 1).to(pooled.dtype)], dim=1)
+        out = self.lrelu(self.nn3(self.lrelu(feats)))
         if return_trace:
             trace = cfg["trace"] or {}
             trace["global_variables"] = gv

@@ -443,7 +443,7 @@ def edgeconv_dq_gather(mode: int, g: NeighbourTable, dpre: Tensor, H1p: int, dQ:
 
 
 # ------------------------------------------------------------------------------ unfused variant blocks
-ACT_CODES = {"relu": 0, "gelu": 1}
+ACT_CODES = {"relu": 0, "gelu": 1, "leaky_relu": 2, "identity": 3}
 
 
 def edge_rows(g: NeighbourTable) -> Tuple[Tensor, Tensor]:

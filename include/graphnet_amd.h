@@ -165,7 +165,7 @@ int gn_edge_rows(const int32_t* nbr, const int32_t* ovf_centre, const int32_t* o
 int gn_edge_gather_pre(const float* PQ, int32_t H1p, const int32_t* ic, const int32_t* jc, int64_t rows,
                        float* pre, void* stream);
 /* a[r, c] = act(gamma ? LayerNorm(z[r, :C]) : z[r, c]); 0 for C <= c < Cpad and for rows with valid[r] < 0;
- * act: 0 relu, 1 gelu (erf); stats[r] = (mean, rstd) when gamma != NULL; Cpad <= 512. */
+ * act: 0 relu, 1 gelu (erf), 2 leaky relu (0.01), 3 identity; stats[r] = (mean, rstd) when gamma != NULL; Cpad <= 512. */
 int gn_rownorm_act_fwd(const float* z, int64_t ldz, int32_t C, const int32_t* valid, const float* gamma,
                        const float* beta, float eps, int32_t act, float* a, int64_t lda, int32_t Cpad,
                        float* stats, int64_t rows, void* stream);

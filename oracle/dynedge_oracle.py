@@ -379,6 +379,48 @@ class DynEdgeOracle(torch.nn.Module):
         return (x, trace) if return_trace else x
 
 
+class DynEdgeJINSTOracle(torch.nn.Module):
+    """``DynEdgeJINST`` (``models/gnn/dynedge_jinst.py:16-161``) restated on CPU: four DynEdgeConv layers
+    (Linear-LeakyReLU-Linear-LeakyReLU, aggr add, k = 8, re-kNN on latent columns 0:3), skip-cat, nn1 + LeakyReLU,
+    nn2, scatter max/min/sum/mean, cat(h_t, h_x, h_y, h_z, n_pulses), LeakyReLU, nn3, LeakyReLU."""
+
+    def __init__(self, nb_inputs: int, layer_size_scale: int = 4, knn_mode: str = "compat"):
+        super().__init__()
+        c = layer_size_scale
+        l1, l2, l3, l4, l5, l6 = nb_inputs, c * 16 * 2, c * 32 * 2, c * 42 * 2, c * 32 * 2, c * 16 * 2
+        self.nb_outputs = l6
+        self._knn_mode = knn_mode
+
+        def mlp(a, b, cc):
+            return torch.nn.Sequential(torch.nn.Linear(a * 2, b), torch.nn.LeakyReLU(), torch.nn.Linear(b, cc),
+                                       torch.nn.LeakyReLU())
+        self.conv_add1 = _ConvHolder(mlp(l1, l2, l3))
+        self.conv_add2 = _ConvHolder(mlp(l3, l4, l3))
+        self.conv_add3 = _ConvHolder(mlp(l3, l4, l3))
+        self.conv_add4 = _ConvHolder(mlp(l3, l4, l3))
+        self.nn1 = torch.nn.Linear(l3 * 4 + l1, l4)
+        self.nn2 = torch.nn.Linear(l4, l5)
+        self.nn3 = torch.nn.Linear(4 * l5 + 5, l6)
+        self.lrelu = torch.nn.LeakyReLU()
+
+    def forward(self, x, edge_index, batch, n_pulses, forced_edges: Optional[List[Tensor]] = None):
+        B = int(n_pulses.shape[0])
+        h_x, h_y, h_z, h_t = calculate_xyzt_homophily(x, edge_index, batch, B)
+        skips = [x]
+        for l, conv in enumerate([self.conv_add1, self.conv_add2, self.conv_add3, self.conv_add4]):
+            x = edge_conv(x, edge_index, conv.nn, "add")
+            if forced_edges is not None and l + 1 < len(forced_edges):
+                edge_index = forced_edges[l + 1]
+            else:
+                edge_index = knn_graph(x, 8, batch, slice(0, 3), self._knn_mode)
+            skips.append(x)
+        x = self.nn2(self.lrelu(self.nn1(torch.cat(skips, dim=1))))
+        pooled = [scatter_max(x, batch, B), scatter_min(x, batch, B), scatter_sum(x, batch, B), scatter_mean(x, batch, B)]
+        x = torch.cat(pooled + [h_t.reshape(-1, 1), h_x.reshape(-1, 1), h_y.reshape(-1, 1), h_z.reshape(-1, 1),
+                                n_pulses.reshape(-1, 1).to(x.dtype)], dim=1)
+        return self.lrelu(self.nn3(self.lrelu(x)))
+
+
 # --------------------------------------------------------------------------------------
 # Task head + loss (models/task/task.py:272-337, task/reconstruction.py:101-112,
 # training/loss_functions.py:34-60,93-112, utilities/maths.py:6-8)

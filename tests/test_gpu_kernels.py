@@ -461,6 +461,36 @@ def test_gelu_layernorm_variants(oracle, name, mode, tol, act, norm):
             assert norm_err(p.grad, po.grad) < 5e-2, f"{name}: grad {kn}"
 
 
+@pytest.mark.parametrize("name,mode,tol", MODES)
+def test_dynedge_jinst_backbone(oracle, name, mode, tol):
+    """DynEdgeJINST (models/gnn/dynedge_jinst.py:16-161): LeakyReLU edge MLPs, nn2 without activation, pooling
+    order max/min/sum/mean, homophily + pulse count appended; same state-dict keys as the reference class."""
+    import graphnet_amd as g
+    b = _batch(6, seed=41)
+    torch.manual_seed(8)
+    ref = oracle.DynEdgeJINSTOracle(7, layer_size_scale=2)
+    m = g.DynEdgeJINST(7, layer_size_scale=2)
+    assert sorted(m.state_dict().keys()) == sorted(ref.state_dict().keys())
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).set_backend(dtype=name)
+    y, trace = m(b.to(DEV), return_trace=True)
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+    (y * w.to(DEV)).sum().backward()
+    bc = b.to("cpu")
+    forced = [t.edge_index().cpu() for t in trace["graphs"]]
+    assert torch.equal(forced[0], oracle.knn_graph(bc.x, 8, bc.batch, [0, 1, 2]))
+    yo = ref(bc.x, forced[0], bc.batch, bc.n_pulses, forced_edges=forced)
+    (yo * w).sum().backward()
+    assert y.shape == yo.shape == (6, ref.nb_outputs)
+    assert rel_err(y, yo.detach()) < tol
+    for (kn, p), (_, po) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, kn
+        err = rel_err(p.grad, po.grad) if mode == 0 else norm_err(p.grad, po.grad)
+        # bf16: Frobenius-norm gate; 1e-1 because leaky relu passes every (rounded) activation on through four
+        # layers - the first layer's small [64, 14] weight sees the accumulated bf16 noise (measured 7e-2)
+        assert err < (2e-3 if mode == 0 else 1e-1), f"{name}: grad {kn}: {err}"
+
+
 # ------------------------------------------------------------------------------ pooling
 def test_segment_pool_forward_backward(oracle):
     from graphnet_amd import ops
