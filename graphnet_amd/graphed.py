@@ -12,9 +12,10 @@ Semantics are those of ``StandardModel.fit``'s eager loop (``models/easy_model.p
 
 Status: EXPERIMENTAL, off by default (``bench.py --graph``).  At test scale (24 events) the replay follows
 the eager loop to ~1e-6 in the loss (not bit for bit: the library GEMMs of the tiny read-out pick other
-algorithms under capture).  At bench scale (1024 events) twenty replays enqueued back to back raised "Memory access fault ... write access to
-a read-only page" (ten did not; synchronised replays never did), hence the in-flight limit below; nothing in
-the default path depends on this module.
+algorithms under capture).  At bench scale (1024 events) the replays 7..26 of one graph raised "Memory access fault ... write access to a
+read-only page" (the first ten replays never do, with or without host synchronisation, and limiting the
+replays in flight to two does not help), so the cause is still open; nothing in the default path depends on
+this module.
 At least one eager warm-up step is required: the optimizer creates its state on the first ``step()``, and
 state created *inside* the capture would be re-initialised by every replay.
 """
@@ -94,9 +95,7 @@ class GraphedTrainStep:
             for k, v in batch.items():
                 if isinstance(v, torch.Tensor):
                     static[k].copy_(v, non_blocking=True)
-        # At most MAX_IN_FLIGHT replays are queued: twenty replays (~5000 kernel nodes) enqueued back to back
-        # faulted the GPU ("write access to a read-only page") while ten did not, so the runtime seems to run
-        # out of some per-launch resource; waiting for the replay before the previous one costs nothing.
+        # At most MAX_IN_FLIGHT replays are queued (keeps the host from running arbitrarily far ahead).
         if len(self._events) >= self.MAX_IN_FLIGHT:
             self._events.pop(0).synchronize()
         g1.replay()
