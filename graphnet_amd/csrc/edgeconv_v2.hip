@@ -321,9 +321,17 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
     constexpr int NI = (NBH * 4 + 7) / 8;           // 16-byte chunks per thread (8 threads per row)
     constexpr int HP = tr_pitch(NBH * 64);
     __shared__ __attribute__((aligned(16))) unsigned char Hs[2][V2_ROWS * HP];
+    __shared__ __attribute__((aligned(16))) unsigned char MaskLut[256 * 16];   // byte -> 8 x (0 / 0xFFFF) halfwords
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
+    if (tid < 256) {
+        u32x4 e;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            e[jj] = ((tid >> (2 * jj)) & 1 ? 0x0000ffffu : 0u) | ((tid >> (2 * jj + 1)) & 1 ? 0xffff0000u : 0u);
+        *reinterpret_cast<u32x4*>(&MaskLut[tid * 16]) = e;
+    }
     const long long ldpq = 2LL * K;
     const long long main_rows = (long long)g.N * S;
     const bool wave_on = wave * 32 < H2;
@@ -419,14 +427,10 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
                 const unsigned int gbf = pack_bf16x2(ga[s], ga[s]);
                 const unsigned int m = (ma >> (8 * s)) & 0xffu;
                 bsum += ga[s] * (float)__builtin_popcount(m);
-                u32x4 aw;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int b0 = __builtin_amdgcn_sbfe((int)m, 2 * jj, 1);
-                    const int b1 = __builtin_amdgcn_sbfe((int)m, 2 * jj + 1, 1);
-                    const unsigned int mk = ((unsigned int)b1 & 0xffff0000u) | ((unsigned int)b0 & 0x0000ffffu);
-                    aw[jj] = gbf & mk;
-                }
+                // 8 slot bits -> 8 bf16 lane masks: one 16-byte LDS lookup instead of 16 bit-field extracts
+                const u32x4 mk = *reinterpret_cast<const u32x4*>(&MaskLut[m * 16]);
+                const u32x4 gb4 = {gbf, gbf, gbf, gbf};
+                const u32x4 aw = gb4 & mk;
                 const bf16x8 afrag = __builtin_bit_cast(bf16x8, aw);
 #pragma unroll
                 for (int nb = 0; nb < NBH; ++nb) {
