@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph (experimental) instead of eager launches")
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-op HIP events (roofline)")
+    ap.add_argument("--extra-events", type=int, default=4096,
+                    help="also report events/s at this many events per GPU (SURVEY 8d: B in {256,1024,4096}); 0 = skip")
     ap.add_argument("--cpu-events", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
@@ -217,6 +219,35 @@ def main():
     timers = ops.timer_summary()
     ops.enable_timers(False)
     prof_steps = max(1, args.profile_steps)
+    # second batch size (same model, same step), reported beside the headline value
+    extra = None
+    if args.extra_events and args.extra_events != args.events:
+        big = synthetic_icecube86_batch(args.extra_events, seed=20241016 + 1000 + rank).to(dev)
+        saved_batch = batch
+
+        def big_step():
+            sync.zero_grad()
+            loss_b = model.shared_step(big)
+            loss_b.backward()
+            sync()
+            opt.step()
+        for i in range(30):
+            big_step()
+            if i % 10 == 9:
+                torch.cuda.synchronize()
+        fence()
+        tb = time.perf_counter()
+        for _ in range(10):
+            big_step()
+        fence()
+        tbig = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tbig, op=dist.ReduceOp.MAX)
+        extra = {"events_per_gpu": args.extra_events, "pulses_per_gpu": int(big.x.shape[0]), "steps": 10,
+                 "value": args.extra_events * world * 10 / float(tbig.item()), "unit": "events/s",
+                 "ms_per_step": 1e3 * float(tbig.item()) / 10}
+        del big
+        batch = saved_batch
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -290,6 +321,7 @@ def main():
             "launch": launch, "host_issue_ms": host_issue_ms,
             "final_loss": float(loss.detach()),
             "measured_peaks": measured_peaks(dev),
+            "other_batch_size": extra,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_events, args.cpu_steps)
