@@ -18,6 +18,10 @@
 //   dq_gather   dQ[j] = sum of dpre rows that gathered from j, in ascending row order
 //               (reverse adjacency, deterministic).
 //
+// This file: the generic tiled kernels (any width, fp32 mode, overflow rows) and the dQ gather; the
+// persistent operand-stationary bf16 kernels for the table rows of the usual shapes are in edgeconv_v2.hip.
+// out / g_out / dP / dQ are stored in the compute type T (fp32 or bf16, see include/graphnet_amd.h).
+//
 // Edge rows: fixed-stride neighbour table nbr[N,K] (-1 padded) viewed as N*S rows, S = slots
 // per centre (8/16/32 >= K); the rare (K+1)-th neighbour of the k+1-then-mask semantics is an
 // "overflow" row t (centre ovf_centre[t], source ovf_src[t]) processed by the OVF variants.

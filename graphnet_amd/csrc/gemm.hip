@@ -1,10 +1,13 @@
 // graphnet_amd/csrc/gemm.hip — per-node dense contractions on MFMA.
 //
 //   gemm_nt   C[M,N]  = epi( sum_seg A_seg[M,K_seg] . W[N, K]^T + bias )      (torch.nn.Linear)
-//             A is a list of fp32 column segments (skip-cat without the cat, dynedge.py:327-331),
-//             W is pre-packed as T[Npad][Kpad] with every segment padded to a multiple of 32.
+//             A is a list of column segments (skip-cat without the cat, dynedge.py:327-331) of fp32 rows
+//             or, in bf16 mode, bf16 rows (activations are stored in the compute type, see graphnet_amd.h);
+//             W is pre-packed as T[Npad][Kpad] with every segment padded to a multiple of 32 (64 in bf16).
+//             Short single-segment contractions in bf16 go to the weights-stationary kernel of gemm_v2.hip.
 //   gemm_tn   dW[N1,K] = sum_m dY[m,N1] . X_seg[m,K]          (weight gradients, split over m,
-//             per-split slabs reduced in fixed order -> bitwise reproducible)
+//             per-split slabs reduced in fixed order -> bitwise reproducible); bf16 mode: the persistent
+//             gemm_tn_v2 kernel (transposed LDS reads, bias gradient from a ones block)
 //   colsum / reduce_slabs   bias gradients and the split reductions.
 //
 // Tiling: 256 threads = 4 waves (2x2), BM x BN x 32 LDS tiles, 32x32 MFMA accumulators.
@@ -524,15 +527,10 @@ static hipError_t launch_gemm_nt_t(const Segs& a, int M, const void* Wp, int Kp,
                                    void* C, long long ldc, hipStream_t st) {
     if (M == 0) return hipSuccess;
     if constexpr (sizeof(T) == 2) {
-        // bf16: 64-deep LDS blocks when every segment allows it (twice the MFMAs per barrier) and a
-        // 256-wide N tile when that does not add padding (A is staged once for all of it)
+        // bf16: 64-deep LDS blocks when every segment allows it (twice the MFMAs per barrier).  A 256-wide N
+        // tile was measured slower (fewer workgroups in flight) and is not instantiated.
         bool k64 = (Kp % 64) == 0;
         for (int s = 0; s < a.nseg; ++s) k64 = k64 && (a.kpad[s] % 64) == 0;
-        static const bool allow_wide = getenv("GN_GEMM_WIDE") && getenv("GN_GEMM_WIDE")[0] == '1';   // measured slower
-        static const bool allow_k64 = !(getenv("GN_GEMM_K64") && getenv("GN_GEMM_K64")[0] == '0');
-        k64 = k64 && allow_k64;
-        const bool wide = allow_wide && cdiv_(Nreal, 256) * 256 <= cdiv_(Nreal, 128) * 128 && cdiv_(Nreal, 256) * 256 <= Npad;
-        if (k64 && wide) return launch_gemm_nt_cfg<T, 256, 64, OutT, AT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
         if (k64) return launch_gemm_nt_cfg<T, 128, 64, OutT, AT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
     }
     return launch_gemm_nt_cfg<T, 128, 32, OutT, AT>(a, M, Wp, Kp, Npad, Nreal, epi, C, ldc, st);
