@@ -9,7 +9,7 @@ from .data import Batch, Data, collate_fn  # noqa: F401
 from .detector import Detector, IceCube86, IceCubeDeepCore, IceCubeUpgrade, ORCA150SuperDense, Prometheus  # noqa: F401
 from .model import Model, ModelConfig  # noqa: F401
 from .graphs import GraphDefinition, KNNEdges, KNNGraph, NodesAsPulses  # noqa: F401
-from .gnn import GNN, DynEdge, DynEdgeJINST  # noqa: F401
+from .gnn import GNN, DynEdge, DynEdgeConv, DynEdgeJINST  # noqa: F401
 from .standard_model import (  # noqa: F401
     EnergyReconstruction, IdentityTask, LogCoshLoss, LossFunction, MSELoss, PiecewiseLinearLR,
     StandardLearnedTask, StandardModel, Task,

@@ -223,6 +223,23 @@ int gn_slot_sum(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, cons
                                     ldo, S(stream)), "gn_slot_sum");
 }
 
+int gn_slot_reduce(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, const int32_t* ovf_centre,
+                   const int32_t* ovf_src, const int32_t* ovf_cnt, int32_t N, int32_t K, const int32_t* jc, int32_t aggr,
+                   float* out, int64_t ldo, int32_t* ovf_row, int32_t* deg, int32_t* argrow, void* stream) {
+    if (K < 1 || K > 32) return bad("gn_slot_reduce", "need 1<=K<=32");
+    hipError_t r = gn::launch_slot_reduce(m, ldm, C, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), gn::edge_slots(K),
+                                          jc, aggr, out, ldo, ovf_row, deg, argrow, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_slot_reduce", "aggr in 0..2, ovf_row / deg required, argrow for max");
+    return fail(r, "gn_slot_reduce");
+}
+int gn_slot_reduce_bwd(const float* gout, int64_t ldg, int32_t C, const int32_t* ic, const int32_t* jc, int64_t rows,
+                       int32_t aggr, const int32_t* deg, const int32_t* argrow, float* grows, int64_t ldr, int32_t Cpad,
+                       void* stream) {
+    hipError_t r = gn::launch_slot_reduce_bwd(gout, ldg, C, ic, jc, rows, aggr, deg, argrow, grows, ldr, Cpad, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_slot_reduce_bwd", "aggr in 0..2, deg for mean, argrow for max, Cpad >= C");
+    return fail(r, "gn_slot_reduce_bwd");
+}
+
 int gn_pack_weights(const int64_t* desc, int32_t ndesc, void* stream) {
     if (ndesc < 0 || (ndesc > 0 && !desc)) return bad("gn_pack_weights", "descriptor table");
     return fail(gn::launch_pack_weights(reinterpret_cast<const long long*>(desc), ndesc, S(stream)), "gn_pack_weights");

@@ -201,6 +201,74 @@ __global__ __launch_bounds__(256) void slot_sum_ovf_kernel(const float* __restri
     out[(long long)g.ovf_centre[q] * ldo + c] += m[((long long)g.N * S + q) * ldm + c];    // <= 1 overflow row per centre
 }
 
+// ---------------------------------------------------------------- aggregation over a centre's edge rows
+// aggr: 0 = add, 1 = mean (sum / number of edges), 2 = max (first occurrence; centres without edges -> 0).
+// rows of centre i: i*S .. i*S+S-1 plus its overflow row N*S + q (ovf_of[i] = q or -1).  jc[row] < 0 = no edge.
+// argrow[i, c] (aggr = max): the row that supplied the maximum (-1: none).
+__global__ __launch_bounds__(256) void slot_reduce_kernel(const float* __restrict__ m, long long ldm, int C, int N, int S,
+                                                          const int* __restrict__ jc, const int* __restrict__ ovf_row,
+                                                          int aggr, float* __restrict__ out, long long ldo,
+                                                          int* __restrict__ argrow) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(t / C), c = (int)(t % C);
+    if (i >= N) return;
+    float acc = aggr == 2 ? -3.0e38f : 0.0f;
+    int arg = -1, cnt = 0;
+    for (int k = 0; k <= S; ++k) {
+        long long row;
+        if (k < S) row = (long long)i * S + k;
+        else { const int q = ovf_row ? ovf_row[i] : -1; if (q < 0) break; row = (long long)N * S + q; }
+        if (jc[row] < 0) continue;
+        const float v = m[row * ldm + c];
+        ++cnt;
+        if (aggr == 2) { if (v > acc) { acc = v; arg = (int)row; } }
+        else acc += v;
+    }
+    if (aggr == 1) acc = cnt > 0 ? acc / (float)cnt : 0.0f;
+    if (aggr == 2 && arg < 0) acc = 0.0f;
+    out[(long long)i * ldo + c] = acc;
+    if (argrow) argrow[(long long)i * C + c] = arg;
+}
+// ovf_row[i] = index q of centre i's overflow row, -1 if none
+__global__ __launch_bounds__(256) void ovf_row_kernel(EdgeGraph g, int* __restrict__ ovf_row) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < g.N) ovf_row[i] = -1;
+}
+__global__ __launch_bounds__(256) void ovf_row_fill_kernel(EdgeGraph g, int* __restrict__ ovf_row) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (g.ovf_cnt && q < *g.ovf_cnt) ovf_row[g.ovf_centre[q]] = q;
+}
+// g_rows[r, c] = d(loss)/d m[r, c] given gout[N, C]: add -> gout[ic]; mean -> gout[ic] / edges(ic);
+// max -> gout[ic] only on the arg row.  Rows without an edge -> 0.  deg[i] = number of edges of centre i.
+__global__ __launch_bounds__(256) void slot_reduce_bwd_kernel(const float* __restrict__ gout, long long ldg, int C,
+                                                              const int* __restrict__ ic, const int* __restrict__ jc,
+                                                              long long rows, int aggr, const int* __restrict__ deg,
+                                                              const int* __restrict__ argrow, float* __restrict__ grows,
+                                                              long long ldr, int Cpad) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long r = t / Cpad;
+    const int c = (int)(t % Cpad);
+    if (r >= rows) return;
+    float v = 0.0f;
+    if (c < C && jc[r] >= 0) {
+        const int i = ic[r];
+        const float go = gout[(long long)i * ldg + c];
+        if (aggr == 0) v = go;
+        else if (aggr == 1) v = go / (float)max(deg[i], 1);
+        else v = (argrow[(long long)i * C + c] == (int)r) ? go : 0.0f;
+    }
+    grows[r * ldr + c] = v;
+}
+__global__ __launch_bounds__(256) void centre_degree_kernel(const int* __restrict__ jc, int N, int S,
+                                                            const int* __restrict__ ovf_row, int* __restrict__ deg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    int d = 0;
+    for (int k = 0; k < S; ++k) d += jc[(long long)i * S + k] >= 0;
+    if (ovf_row && ovf_row[i] >= 0) d += jc[(long long)N * S + ovf_row[i]] >= 0;
+    deg[i] = d;
+}
+
 }  // namespace gn
 
 // =============================================================== launchers
@@ -249,6 +317,27 @@ hipError_t launch_rownorm_act_bwd(const float* g, long long ldg, const int* gidx
     if (norm) { if (act == 0) GN_RN_BWD(true, 0); else if (act == 1) GN_RN_BWD(true, 1); else if (act == 2) GN_RN_BWD(true, 2); else GN_RN_BWD(true, 3); }
     else { if (act == 0) GN_RN_BWD(false, 0); else if (act == 1) GN_RN_BWD(false, 1); else if (act == 2) GN_RN_BWD(false, 2); else GN_RN_BWD(false, 3); }
 #undef GN_RN_BWD
+    return hipGetLastError();
+}
+// ovf_row, deg: int32[N] outputs (per graph, reusable); argrow: int32[N*C] output for aggr = max (else null)
+hipError_t launch_slot_reduce(const float* m, long long ldm, int C, const EdgeGraph& g, int S, const int* jc, int aggr,
+                              float* out, long long ldo, int* ovf_row, int* deg, int* argrow, hipStream_t st) {
+    if (g.N == 0) return hipSuccess;
+    if (aggr < 0 || aggr > 2 || (aggr == 2 && !argrow) || !ovf_row || !deg) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ovf_row_kernel, dim3(gblocks(g.N, 256)), dim3(256), 0, st, g, ovf_row);
+    if (g.ovf_cnt) hipLaunchKernelGGL(ovf_row_fill_kernel, dim3(gblocks(g.N, 256)), dim3(256), 0, st, g, ovf_row);
+    hipLaunchKernelGGL(centre_degree_kernel, dim3(gblocks(g.N, 256)), dim3(256), 0, st, jc, g.N, S, ovf_row, deg);
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3(gblocks((long long)g.N * C, 256)), dim3(256), 0, st, m, ldm, C, g.N, S, jc,
+                       ovf_row, aggr, out, ldo, argrow);
+    return hipGetLastError();
+}
+hipError_t launch_slot_reduce_bwd(const float* gout, long long ldg, int C, const int* ic, const int* jc, long long rows,
+                                  int aggr, const int* deg, const int* argrow, float* grows, long long ldr, int Cpad,
+                                  hipStream_t st) {
+    if (rows == 0) return hipSuccess;
+    if (aggr < 0 || aggr > 2 || Cpad < C || (aggr == 1 && !deg) || (aggr == 2 && !argrow)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(slot_reduce_bwd_kernel, dim3(gblocks(rows * Cpad, 256)), dim3(256), 0, st, gout, ldg, C, ic, jc, rows,
+                       aggr, deg, argrow, grows, ldr, Cpad);
     return hipGetLastError();
 }
 hipError_t launch_slot_sum(const float* m, long long ldm, int C, const EdgeGraph& g, int S, float* out, long long ldo,

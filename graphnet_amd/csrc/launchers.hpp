@@ -58,6 +58,11 @@ hipError_t launch_rownorm_act_bwd(const float* g, long long ldg, const int* gidx
                                   const int* valid, const float* gamma, const float* beta, const float* stats, int act,
                                   float* dz, long long lddz, int Cpad, float* t_dy, float* t_dyx, long long rows,
                                   hipStream_t st);
+hipError_t launch_slot_reduce(const float* m, long long ldm, int C, const EdgeGraph& g, int S, const int* jc, int aggr,
+                              float* out, long long ldo, int* ovf_row, int* deg, int* argrow, hipStream_t st);
+hipError_t launch_slot_reduce_bwd(const float* gout, long long ldg, int C, const int* ic, const int* jc, long long rows,
+                                  int aggr, const int* deg, const int* argrow, float* grows, long long ldr, int Cpad,
+                                  hipStream_t st);
 hipError_t launch_slot_sum(const float* m, long long ldm, int C, const EdgeGraph& g, int S, float* out, long long ldo,
                            hipStream_t st);
 // pool.hip

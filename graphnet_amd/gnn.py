@@ -820,3 +820,152 @@ class DynEdgeJINST(GNN):
             trace["global_variables"] = gv
             return out, trace
         return out
+
+
+# ------------------------------------------------------------------------------ stand-alone DynEdgeConv layer
+_ACT_NAMES = {torch.nn.ReLU: "relu", torch.nn.GELU: "gelu", torch.nn.LeakyReLU: "leaky_relu", torch.nn.Identity: "identity"}
+
+
+class _EdgeConvFunction(torch.autograd.Function):
+    """One EdgeConv (``x_i' = aggr_j nn([x_i || x_j - x_i])``, two-layer ``nn``) on the unfused kernels;
+    differentiable w.r.t. ``x`` and every parameter.  ``params``: W1, b1, [g1, be1], W2, b2, [g2, be2]."""
+
+    @staticmethod
+    def forward(ctx, cfg: dict, x: Tensor, *params: Tensor) -> Tensor:  # type: ignore[override]
+        mode, g, aggr, norm = cfg["mode"], cfg["graph"], cfg["aggr"], cfg["norm"]
+        act1, act2 = cfg["acts"]
+        dt, ku = ops.mode_dtype(mode), ops.gemm_kunit(mode)
+        step = 4 if norm else 2
+        p1, p2 = params[:step], params[step:]
+        W1, b1, W2, b2 = p1[0], p1[1], p2[0], p2[1]
+        ln1 = (p1[2], p1[3]) if norm else (None, None)
+        ln2 = (p2[2], p2[3]) if norm else (None, None)
+        N, Fin = int(x.shape[0]), int(x.shape[1])
+        xin = torch.zeros((N, ops.round_up(Fin, 32)), dtype=torch.float32, device=x.device)
+        xin[:, :Fin] = x
+        H1, H2 = int(W1.shape[0]), int(W2.shape[0])
+        H1p, H2r = ops.round_up(H1, 32), ops.round_up(H2, 8)
+        Wa, Wb = W1[:, :Fin], W1[:, Fin:]
+        Wpq = torch.zeros((2 * H1p, Fin), dtype=torch.float32, device=x.device)
+        Wpq[:H1] = Wa - Wb
+        Wpq[H1p:H1p + H1] = Wb
+        bpq = torch.zeros(2 * H1p, dtype=torch.float32, device=x.device)
+        bpq[:H1] = b1
+        PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), ops.pack_weight(Wpq, [Fin], dt, ku), 2 * H1p, bias=bpq)
+        ic, jc = ops.edge_rows(g)
+        pre1 = ops.edge_gather_pre(PQ, H1p, ic, jc)
+        a1, st1 = ops.rownorm_act_fwd(pre1, H1, act1, ln1[0], ln1[1], valid=jc, cpad=H1p)
+        z2 = ops.linear_fwd(mode, [(a1, H1p)], ops.pack_weight(W2, [H1], dt, ku), H2, bias=b2.contiguous(), out_cols=H2r)
+        m, st2 = ops.rownorm_act_fwd(z2, H2, act2, ln2[0], ln2[1], valid=jc, cpad=H2r)
+        out, aux = ops.slot_reduce(m, H2, g, aggr)
+        ctx.cfg, ctx.params, ctx.saved = cfg, params, (xin, Fin, pre1, a1, st1, z2, st2, aux)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):  # type: ignore[override]
+        cfg, params = ctx.cfg, ctx.params
+        mode, g, aggr, norm = cfg["mode"], cfg["graph"], cfg["aggr"], cfg["norm"]
+        act1, act2 = cfg["acts"]
+        dt, ku = ops.mode_dtype(mode), ops.gemm_kunit(mode)
+        step = 4 if norm else 2
+        p1, p2 = params[:step], params[step:]
+        W1, W2 = p1[0], p2[0]
+        ln1 = (p1[2], p1[3]) if norm else (None, None)
+        ln2 = (p2[2], p2[3]) if norm else (None, None)
+        xin, Fin, pre1, a1, st1, z2, st2, aux = ctx.saved
+        N, dev = int(xin.shape[0]), xin.device
+        H1, H2 = int(W1.shape[0]), int(W2.shape[0])
+        H1p, H2r = ops.round_up(H1, 32), ops.round_up(H2, 8)
+        ic, jc = ops.edge_rows(g)
+        grows = ops.slot_reduce_bwd(gout.contiguous().to(torch.float32), H2, g, aggr, aux, cpad=H2r)
+        dz2, dg2, db2n = ops.rownorm_act_bwd(grows, z2, H2, act2, ln2[0], ln2[1], st2, valid=jc, cpad=H2r)
+        dW2, db2 = ops.linear_wgrad(mode, dz2, H2, [(a1, H1p)], with_bias=True)
+        da1 = ops.linear_fwd(mode, _ksegs([(dz2, H2)]), ops.pack_weight(W2.t(), [H2], dt, ku), H1, out_cols=H1p)
+        dpre1, dg1, db1n = ops.rownorm_act_bwd(da1, pre1, H1, act1, ln1[0], ln1[1], st1, valid=jc, cpad=H1p)
+        dPQ = torch.empty((N, 2 * H1p), dtype=torch.float32, device=dev)
+        dPQ[:, :H1p] = ops.slot_sum(dpre1, H1p, g)
+        ops.edgeconv_dq_gather(ops.MODE_F32, g, dpre1, H1p, dPQ[:, H1p:])
+        dWpq, dbpq = ops.linear_wgrad(mode, dPQ, 2 * H1p, _ksegs([(xin, Fin)]), with_bias=True)
+        dWpq = dWpq[:, :Fin]
+        dWp, dWq = dWpq[:H1], dWpq[H1p:H1p + H1]
+        grads: List[Optional[Tensor]] = [None] * len(params)
+        grads[0] = torch.cat([dWp, dWq - dWp], dim=1)
+        grads[1] = dbpq[:H1]
+        grads[step] = dW2[:, :H1]
+        grads[step + 1] = db2
+        if norm:
+            grads[2], grads[3], grads[step + 2], grads[step + 3] = dg1, db1n, dg2, db2n
+        dx = None
+        if ctx.needs_input_grad[1]:
+            Wa, Wb = W1[:, :Fin], W1[:, Fin:]
+            WpqT = torch.zeros((Fin, 2 * H1p), dtype=torch.float32, device=dev)
+            WpqT[:, :H1] = (Wa - Wb).t()
+            WpqT[:, H1p:H1p + H1] = Wb.t()
+            dx = ops.linear_fwd(mode, [(dPQ, 2 * H1p)], ops.pack_weight(WpqT, [2 * H1p], dt, ku), Fin,
+                                out_cols=ops.round_up(Fin, 8))[:, :Fin]
+        return (None, dx) + tuple(grads)
+
+
+class DynEdgeConv(torch.nn.Module):
+    """Stand-alone dynamical edge convolution (``models/components/layers.py:20-69``): PyG ``EdgeConv`` with
+    ``aggr`` in add / mean / max (reference default "max") followed by a k-NN re-clustering on
+    ``features_subset`` of the new features.  ``nn`` must be ``Linear, [LayerNorm], act, Linear, [LayerNorm], act``
+    with act in ReLU / GELU / LeakyReLU / Identity.  Runs on the unfused kernels (``csrc/generic.hip``); the
+    fused fast path is used by :class:`DynEdge` as a whole.
+
+    ``forward(x, edge_index, batch)`` accepts a ``[2, E]`` ``edge_index`` (grouped by target, in-degree
+    <= nb_neighbors + 1) or a :class:`ops.NeighbourTable`; it returns ``(x', table)`` where ``table.edge_index()``
+    materialises the PyG tensor the reference returns."""
+
+    def __init__(self, nn: torch.nn.Module, aggr: str = "max", nb_neighbors: int = 8,
+                 features_subset: Optional[Union[Sequence[int], slice]] = None, **kwargs: Any):
+        super().__init__()
+        if features_subset is None:
+            features_subset = slice(None)
+        assert isinstance(features_subset, (list, slice))
+        if aggr not in ops.AGGR_CODES:
+            raise ValueError(f"aggr {aggr!r} not supported")
+        self.nn = nn
+        self.aggr = aggr
+        self.nb_neighbors = nb_neighbors
+        self.features_subset = features_subset
+        self._compute_mode = ops.MODE_BF16
+        mods = list(nn) if isinstance(nn, torch.nn.Sequential) else None
+        lin = [m for m in (mods or []) if isinstance(m, torch.nn.Linear)]
+        norms = [m for m in (mods or []) if isinstance(m, torch.nn.LayerNorm)]
+        acts = [m for m in (mods or []) if type(m) in _ACT_NAMES]
+        if mods is None or len(lin) != 2 or len(acts) != 2 or len(norms) not in (0, 2) or \
+                len(mods) != 4 + len(norms) or any(isinstance(m, torch.nn.LeakyReLU) and m.negative_slope != 0.01 for m in acts):
+            raise NotImplementedError("graphnet_amd.DynEdgeConv: nn must be Linear, [LayerNorm], act, Linear, [LayerNorm], act "
+                                      "(act: ReLU / GELU / LeakyReLU(0.01) / Identity); there is no fallback")
+        self._lin, self._norms = lin, norms
+        self._acts = (_ACT_NAMES[type(acts[0])], _ACT_NAMES[type(acts[1])])
+
+    def set_backend(self, dtype: str) -> "DynEdgeConv":
+        self._compute_mode = {"fp32": ops.MODE_F32, "bf16": ops.MODE_BF16}[dtype]
+        return self
+
+    def forward(self, x: Tensor, edge_index: Any, batch: Optional[Tensor] = None):
+        if not x.is_cuda:
+            raise RuntimeError("graphnet_amd.DynEdgeConv runs on an MI355X (HIP) device only")
+        N = int(x.shape[0])
+        table = edge_index if isinstance(edge_index, ops.NeighbourTable) else \
+            ops.table_from_edge_index(edge_index, N, self.nb_neighbors)
+        params: List[Tensor] = []
+        for i, lin in enumerate(self._lin):
+            params += [lin.weight, lin.bias]
+            if self._norms:
+                params += [self._norms[i].weight, self._norms[i].bias]
+        cfg = {"mode": self._compute_mode, "graph": table, "aggr": self.aggr, "norm": bool(self._norms), "acts": self._acts}
+        out = _EdgeConvFunction.apply(cfg, x.to(torch.float32), *params)
+        # re-cluster (layers.py:63-67)
+        if batch is None:
+            batch = torch.zeros(N, dtype=torch.int64, device=x.device)
+        B = int(batch.max().item()) + 1 if N else 0
+        ptr = torch.zeros(B + 1, dtype=torch.int32, device=x.device)
+        ptr[1:] = torch.cumsum(torch.bincount(batch.to(torch.int64), minlength=B), 0).to(torch.int32)
+        cols = _subset_cols(self.features_subset, int(out.shape[1]))
+        if len(cols) > 8:
+            raise NotImplementedError("graphnet_amd.DynEdgeConv: the k-NN kernel takes at most 8 coordinate columns")
+        new_table = ops.knn_graph(out.detach(), cols, batch.to(torch.int32), ptr, self.nb_neighbors)
+        return out, new_table

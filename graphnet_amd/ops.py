@@ -513,6 +513,38 @@ def slot_sum(m: Tensor, C: int, g: NeighbourTable) -> Tensor:
     return out
 
 
+AGGR_CODES = {"add": 0, "sum": 0, "mean": 1, "max": 2}
+
+
+def slot_reduce(m: Tensor, C: int, g: NeighbourTable, aggr: str):
+    """Aggregate the edge rows of every centre (add / mean / max) -> (out [N, C], aux for the backward)."""
+    _need(m, torch.float32, "m")
+    ic, jc = edge_rows(g)
+    dev = m.device
+    out = torch.empty((g.N, C), dtype=torch.float32, device=dev)
+    ovf_row = torch.empty(max(g.N, 1), dtype=torch.int32, device=dev)
+    deg = torch.empty(max(g.N, 1), dtype=torch.int32, device=dev)
+    code = AGGR_CODES[aggr]
+    argrow = torch.empty(max(g.N * C, 1), dtype=torch.int32, device=dev) if code == 2 else None
+    with _timed("generic_edge"):
+        _lib.check(_lib.lib().gn_slot_reduce(_p(m), _rows(m, "m"), C, *g.c_args(), _p(jc), code, _p(out), C, _p(ovf_row),
+                                             _p(deg), _p(argrow), _st()))
+    return out, (deg, argrow)
+
+
+def slot_reduce_bwd(gout: Tensor, C: int, g: NeighbourTable, aggr: str, aux, cpad: Optional[int] = None) -> Tensor:
+    """Gradient of :func:`slot_reduce` w.r.t. the edge rows: [rows, cpad] fp32."""
+    _need(gout, torch.float32, "gout")
+    ic, jc = edge_rows(g)
+    cpad = C if cpad is None else cpad
+    deg, argrow = aux
+    grows = torch.empty((g.rows, cpad), dtype=torch.float32, device=gout.device)
+    with _timed("generic_edge"):
+        _lib.check(_lib.lib().gn_slot_reduce_bwd(_p(gout), _rows(gout, "gout"), C, _p(ic), _p(jc), g.rows, AGGR_CODES[aggr],
+                                                 _p(deg), _p(argrow), _p(grows), cpad, cpad, _st()))
+    return grows
+
+
 # ------------------------------------------------------------------------------ pooling
 def _codes(schemes: Sequence[str]):
     return (ctypes.c_int32 * len(schemes))(*[POOL_CODES[s] for s in schemes])

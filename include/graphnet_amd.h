@@ -180,6 +180,18 @@ int gn_slot_sum(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, cons
                 const int32_t* ovf_src, const int32_t* ovf_cnt, int32_t N, int32_t K, float* out, int64_t ldo,
                 void* stream);
 
+/* EdgeConv aggregation over a centre's edge rows (torch_geometric MessagePassing aggr; DynEdgeConv default "max",
+ * layers.py:20-50): aggr 0 add, 1 mean, 2 max (first occurrence, centres without edges -> 0).  jc from
+ * gn_edge_rows.  Outputs besides out[N, ldo]: ovf_row[N] (overflow row of a centre or -1), deg[N] (edges per
+ * centre), argrow[N*C] (aggr = max only).  gn_slot_reduce_bwd expands gout[N, ldg] to the edge rows. */
+int gn_slot_reduce(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, const int32_t* ovf_centre,
+                   const int32_t* ovf_src, const int32_t* ovf_cnt, int32_t N, int32_t K, const int32_t* jc,
+                   int32_t aggr, float* out, int64_t ldo, int32_t* ovf_row, int32_t* deg, int32_t* argrow,
+                   void* stream);
+int gn_slot_reduce_bwd(const float* gout, int64_t ldg, int32_t C, const int32_t* ic, const int32_t* jc,
+                       int64_t rows, int32_t aggr, const int32_t* deg, const int32_t* argrow, float* grows,
+                       int64_t ldr, int32_t Cpad, void* stream);
+
 /* ---- operand copies of the weights ------------------------------------------------------- */
 /* One launch rewrites every padded / transposed / bf16 copy of the weights the kernels above consume
  * (what torch.nn.Linear does implicitly with its own weight).  desc: DEVICE int64[ndesc][10] =
