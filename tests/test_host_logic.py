@@ -77,6 +77,29 @@ def test_detector_standardisation_and_graph_definition():
     assert torch.equal(a.x, b.x) and not torch.equal(a.x, d.x)
 
 
+def test_detector_programs_equal_the_reference_expressions():
+    """Every per-column op program (shared by the host path and the gn_standardize kernel) reproduces the
+    reference's lambda bit for bit (icecube.py:21-48,116-170; prometheus.py:11-39)."""
+    torch.manual_seed(0)
+    x = (torch.rand(257) * 1200.0 - 600.0).to(torch.float32)
+    q = torch.rand(257) * 30.0 + 0.05
+    expect = {
+        g.IceCube86: {"dom_x": x / 500.0, "dom_time": (x - 1.0e04) / 3.0e4, "charge": torch.log10(q),
+                      "rde": (x - 1.25) / 0.25, "pmt_area": x / 0.05, "hlc": x},
+        g.IceCubeDeepCore: {"dom_x": x / 100.0, "dom_z": (x + 350.0) / 100.0, "dom_time": ((x / 1.05e04) - 1.0) * 20.0,
+                            "charge": q},
+        g.IceCubeUpgrade: {"dom_time": (x / 2e04) - 1.0, "charge": torch.log10(q) / 2.0, "string": (x - 50.0) / 50.0,
+                           "pmt_number": x / 20.0, "dom_number": (x - 60.0) / 60.0, "dom_type": x / 130.0, "rde": x},
+        g.Prometheus: {"sensor_pos_x": x / 100, "sensor_pos_z": (x + 350) / 100, "t": x / 1.05e04},
+    }
+    for cls, cols in expect.items():
+        fmap = cls().feature_map()
+        for name, ref in cols.items():
+            src = q if name == "charge" else x
+            assert torch.equal(fmap[name](src.clone()), ref), (cls.__name__, name)
+            assert len(cls().feature_ops()[name]) <= 3
+
+
 def test_collate_drops_single_pulse_events_and_offsets_edges():
     ds = []
     for n in (4, 1, 3):
