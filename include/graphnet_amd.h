@@ -209,6 +209,18 @@ int gn_segment_pool_bwd(const float* gout, int32_t C, const int32_t* ptr, const 
                         const float* gate, int64_t ldgate, void* dx, int64_t lddx, int32_t dx_lowp, void* stream);
 /* (dx: fp32, or bf16 when dx_lowp) */
 
+/* ---- ragged multi-head self attention (DynTrans, models/components/layers.py:166-197) ---- */
+/* Replaces to_dense_batch + torch.nn.TransformerEncoder's attention + x[mask]: every pulse attends to the
+ * pulses of its own event (ptr), nothing is padded.  qkv[N, ld] fp32 = [Q | K | V], each H*DH wide (the in_proj
+ * output); tile_ptr from gn_knn_plan; out[N, ldo] = softmax(Q K^T / sqrt(DH)) V per head, heads side by side;
+ * lse2[N, H] = log2 of the softmax denominators (saved for the backward).  gn_attention_bwd: dqkv[N, lddq] =
+ * gradient w.r.t. qkv given dout; delta[N, H] is scratch.  DH in {8, 16, 32, 64}. */
+int gn_attention_fwd(const float* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr, const int32_t* tile_ptr,
+                     int32_t B, int32_t N, float* out, int64_t ldo, float* lse2, void* stream);
+int gn_attention_bwd(const float* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr, const int32_t* tile_ptr,
+                     int32_t B, int32_t N, const float* out, int64_t ldo, const float* dout, int64_t lddo,
+                     const float* lse2, float* delta, float* dqkv, int64_t lddq, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

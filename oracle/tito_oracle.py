@@ -1,0 +1,162 @@
+"""oracle/tito_oracle.py — plain-torch CPU restatement of the reference DynEdgeTITO path.
+
+TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` legs of the
+bench scripts may import this module; nothing under ``graphnet_amd/`` does.
+
+Pins: the transformer encoder layer below is a ptr-driven (no padding) restatement of
+``torch.nn.TransformerEncoder(TransformerEncoderLayer(d, n_head, batch_first=True, norm_first=False), 1)`` applied
+to ``to_dense_batch(x, batch)`` with ``src_key_padding_mask=~mask`` (``models/components/layers.py:166-197``).  torch
+itself IS importable here, so ``tests/test_oracle_pins.py`` checks the restatement against that very module
+(eval mode and train mode with dropout 0) — pinned.  ``EdgeConvTito`` (``layers.py:72-114`` on
+torch_geometric ``MessagePassing`` with ``aggr="max"``) and ``to_dense_batch`` come from torch-geometric, absent
+here: PARITY UNPINNED for those two steps, as for ``dynedge_oracle.py``.
+
+Each function cites the reference file:line it follows (paths relative to /root/reference/src/graphnet/).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from .dynedge_oracle import GLOBAL_POOLINGS, calculate_xyzt_homophily, scatter_max, scatter_mean
+
+
+# --------------------------------------------------------------------------------------
+# EdgeConvTito (models/components/layers.py:72-114): message nn([x_i, x_j - x_i, x_j]), aggr max
+# --------------------------------------------------------------------------------------
+def edge_conv_tito(x: Tensor, edge_index: Tensor, nn: torch.nn.Module, aggr: str = "max") -> Tensor:
+    x_i = x.index_select(0, edge_index[1])
+    x_j = x.index_select(0, edge_index[0])
+    msg = nn(torch.cat([x_i, x_j - x_i, x_j], dim=-1))
+    if aggr != "max":
+        raise ValueError(aggr)
+    # PyG's max aggregation leaves 0 for nodes without incoming edges (scatter_max semantics)
+    return scatter_max(msg, edge_index[1], x.shape[0])
+
+
+# --------------------------------------------------------------------------------------
+# one post-norm encoder layer on ragged events (layers.py:166-197 -> torch.nn.TransformerEncoderLayer)
+# --------------------------------------------------------------------------------------
+def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)        # biased, as torch.nn.LayerNorm
+    return (x - mu) / torch.sqrt(var + eps) * weight + bias
+
+
+def self_attention_ragged(x: Tensor, ptr: Sequence[int], in_w: Tensor, in_b: Tensor, out_w: Tensor, out_b: Tensor,
+                          n_head: int) -> Tensor:
+    """Multi-head self attention where every event attends to its own pulses only: what the padded
+    ``[B, Lmax, d]`` tensor + key-padding mask computes for the rows that survive ``x[mask]``."""
+    N, d = x.shape
+    dh = d // n_head
+    qkv = x @ in_w.t() + in_b
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    outs = []
+    for e in range(len(ptr) - 1):
+        a, b = int(ptr[e]), int(ptr[e + 1])
+        n = b - a
+        qe = q[a:b].reshape(n, n_head, dh).transpose(0, 1)          # [H, n, dh]
+        ke = k[a:b].reshape(n, n_head, dh).transpose(0, 1)
+        ve = v[a:b].reshape(n, n_head, dh).transpose(0, 1)
+        s = (qe @ ke.transpose(1, 2)) / math.sqrt(dh)               # [H, n, n]
+        p = torch.softmax(s, dim=-1)
+        outs.append((p @ ve).transpose(0, 1).reshape(n, d))
+    o = torch.cat(outs, dim=0) if outs else x.new_zeros((0, d))
+    return o @ out_w.t() + out_b
+
+
+def encoder_layer_ragged(x: Tensor, ptr: Sequence[int], layer: torch.nn.TransformerEncoderLayer) -> Tensor:
+    """norm_first=False, activation relu, dropout inactive (eval, or p = 0)."""
+    sa = layer.self_attn
+    a = self_attention_ragged(x, ptr, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+                              sa.num_heads)
+    x = layer_norm(x + a, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+    f = torch.relu(x @ layer.linear1.weight.t() + layer.linear1.bias) @ layer.linear2.weight.t() + layer.linear2.bias
+    return layer_norm(x + f, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+
+
+class DynTransOracle(torch.nn.Module):
+    """``DynTrans`` (layers.py:117-197); attribute names give the reference's state-dict keys."""
+
+    def __init__(self, layer_sizes: List[int], n_head: int = 8, dropout: float = 0.1):
+        super().__init__()
+        layers: List[torch.nn.Module] = []
+        for ix, (nb_in, nb_out) in enumerate(zip(layer_sizes[:-1], layer_sizes[1:])):
+            if ix == 0:
+                nb_in *= 3
+            layers.append(torch.nn.Linear(nb_in, nb_out))
+            layers.append(torch.nn.LeakyReLU())
+        d_model = layer_sizes[-1]
+        self.nn = torch.nn.Sequential(*layers)
+        self.norm1 = torch.nn.LayerNorm(d_model, eps=1e-5)
+        enc = torch.nn.TransformerEncoderLayer(d_model=d_model, nhead=n_head, batch_first=True, norm_first=False,
+                                               dropout=dropout)
+        self._transformer_encoder = torch.nn.TransformerEncoder(enc, num_layers=1)
+
+    def forward(self, x: Tensor, edge_index: Tensor, ptr: Sequence[int]) -> Tensor:
+        x_out = edge_conv_tito(x, edge_index, self.nn)
+        x = x + x_out if x_out.shape[-1] == x.shape[-1] else x_out
+        x = layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        return encoder_layer_ragged(x, ptr, self._transformer_encoder.layers[0])
+
+
+class DynEdgeTITOOracle(torch.nn.Module):
+    """CPU restatement of ``models/gnn/dynedge_kaggle_tito.py`` (ctor l.32-138, layers l.140-196,
+    forward l.236-268), dropout inactive."""
+
+    def __init__(self, nb_inputs: int, dyntrans_layer_sizes: Optional[List[Tuple[int, ...]]] = None,
+                 global_pooling_schemes: Sequence[str] = ("max",), use_global_features: bool = True,
+                 use_post_processing_layers: bool = True, post_processing_layer_sizes: Optional[List[int]] = None,
+                 readout_layer_sizes: Optional[List[int]] = None, n_head: int = 8):
+        super().__init__()
+        sizes = dyntrans_layer_sizes or [(256, 256)] * 4
+        post = post_processing_layer_sizes or [336, 256]
+        ro = readout_layer_sizes or [256, 128]
+        self._pools = list(global_pooling_schemes)
+        self._use_globals = use_global_features
+        act = torch.nn.LeakyReLU()
+        self._conv_layers = torch.nn.ModuleList()
+        lat = nb_inputs
+        for s in sizes:
+            self._conv_layers.append(DynTransOracle([lat] + list(s), n_head=n_head))
+            lat = s[-1]
+        self._use_post = use_post_processing_layers
+        if use_post_processing_layers:
+            mods: List[torch.nn.Module] = []
+            ls = [lat] + list(post)
+            for a, b in zip(ls[:-1], ls[1:]):
+                mods += [torch.nn.Linear(a, b), act]
+            self._post_processing = torch.nn.Sequential(*mods)
+            lat = post[-1]
+        lat = lat * len(self._pools) + ((5 + nb_inputs) if use_global_features else 0)
+        mods = []
+        ls = [lat] + list(ro)
+        for a, b in zip(ls[:-1], ls[1:]):
+            mods += [torch.nn.Linear(a, b), act]
+        self._readout = torch.nn.Sequential(*mods)
+
+    def forward(self, x: Tensor, edge_index: Tensor, batch: Tensor, n_pulses: Tensor, return_trace: bool = False):
+        B = int(n_pulses.shape[0])
+        ptr = [0] + torch.cumsum(torch.bincount(batch, minlength=B), 0).tolist()
+        trace = {}
+        if self._use_globals:   # dynedge_kaggle_tito.py:214-234
+            hx, hy, hz, ht = calculate_xyzt_homophily(x, edge_index, batch, B)
+            gv = torch.cat([scatter_mean(x, batch, B), hx, hy, hz, ht,
+                            torch.log10(n_pulses).to(torch.float32).unsqueeze(1)], dim=1)
+            trace["global_variables"] = gv
+        trace["conv_out"] = []
+        for conv in self._conv_layers:
+            x = conv(x, edge_index, ptr)
+            trace["conv_out"].append(x)
+        if self._use_post:
+            x = self._post_processing(x)
+        trace["post"] = x
+        x = torch.cat([GLOBAL_POOLINGS[s](x, batch, B) for s in self._pools], dim=1)
+        trace["pooled"] = x
+        if self._use_globals:
+            x = torch.cat([x, gv], dim=1)
+        x = self._readout(x)
+        return (x, trace) if return_trace else x

@@ -1,6 +1,7 @@
 """CPU: pin the oracle against every known answer the reference's own tests hold for this path
  and against the committed golden fixtures."""
 import numpy as np
+import pytest
 import torch
 
 
@@ -91,3 +92,63 @@ def test_golden_expected_reproduced(oracle, golden):
             assert np.array_equal(nbr.numpy(), ex[f"{name}_nbr_{mode}"])
     # real data has > k pulses on one DOM: the k+1 case is exercised by the reference's own events
     assert (ex["upgrade_nbr_compat"][:, 8] >= 0).any()
+
+
+def _dense(x, ptr):
+    """to_dense_batch restated: [B, Lmax, d] zero padded + mask (used only to feed torch's own encoder)."""
+    B = len(ptr) - 1
+    L = max(ptr[e + 1] - ptr[e] for e in range(B))
+    dense = x.new_zeros((B, L, x.shape[1]))
+    mask = torch.zeros((B, L), dtype=torch.bool)
+    for e in range(B):
+        n = ptr[e + 1] - ptr[e]
+        dense[e, :n] = x[ptr[e]:ptr[e + 1]]
+        mask[e, :n] = True
+    return dense, mask
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_ragged_encoder_layer_equals_torch_transformer_encoder(train):
+    """Pins ``tito_oracle.encoder_layer_ragged`` against the module the reference calls
+    (``layers.py:166-197``: TransformerEncoder on the padded batch, key-padding mask, ``x[mask]``)."""
+    from oracle import tito_oracle
+    torch.manual_seed(3)
+    d, H = 64, 8
+    layer = torch.nn.TransformerEncoderLayer(d_model=d, nhead=H, batch_first=True, norm_first=False, dropout=0.0,
+                                             dim_feedforward=128)
+    enc = torch.nn.TransformerEncoder(layer, num_layers=1)
+    enc.train(train)
+    ptr = [0, 5, 6, 23, 40]
+    x = torch.randn(ptr[-1], d, requires_grad=True)
+    dense, mask = _dense(x, ptr)
+    want = enc(dense, src_key_padding_mask=~mask)[mask]
+    x2 = x.detach().clone().requires_grad_(True)
+    got = tito_oracle.encoder_layer_ragged(x2, ptr, enc.layers[0])
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), float((got - want).abs().max())
+    if train:
+        w = torch.randn_like(want)
+        (want * w).sum().backward()
+        gref = [p.grad.clone() for p in enc.parameters()]
+        for p in enc.parameters():
+            p.grad = None
+        (got * w).sum().backward()
+        assert torch.allclose(x2.grad, x.grad, rtol=1e-4, atol=1e-5)
+        for p, gr in zip(enc.parameters(), gref):
+            assert torch.allclose(p.grad, gr, rtol=1e-4, atol=1e-4)
+
+
+def test_tito_oracle_state_dict_keys_match_the_reference_layout():
+    """Key names per ``dynedge_kaggle_tito.py:140-196`` / ``layers.py:117-164``."""
+    from oracle import tito_oracle
+    m = tito_oracle.DynEdgeTITOOracle(7, dyntrans_layer_sizes=[(32, 32), (32, 32)], post_processing_layer_sizes=[48, 32],
+                                      readout_layer_sizes=[32, 16], n_head=4)
+    keys = set(m.state_dict())
+    for k in ("_conv_layers.0.nn.0.weight", "_conv_layers.0.nn.2.bias", "_conv_layers.1.norm1.weight",
+              "_conv_layers.0._transformer_encoder.layers.0.self_attn.in_proj_weight",
+              "_conv_layers.0._transformer_encoder.layers.0.self_attn.out_proj.bias",
+              "_conv_layers.0._transformer_encoder.layers.0.linear1.weight",
+              "_conv_layers.0._transformer_encoder.layers.0.norm2.bias",
+              "_post_processing.0.weight", "_post_processing.2.bias", "_readout.0.weight", "_readout.2.bias"):
+        assert k in keys, k
+    assert m.state_dict()["_conv_layers.0.nn.0.weight"].shape == (32, 21)
+    assert m.state_dict()["_readout.0.weight"].shape == (32, 32 + 12)
