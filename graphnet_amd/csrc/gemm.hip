@@ -649,8 +649,11 @@ hipError_t launch_gemm_tn(int mode, const void* dY, int dy_lowp, long long lddy,
     hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, st, (const float*)dY, lddy, N1, x, M, rps, slab, Ktot, n1t);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(count, RS_ELEMS)), dim3(256), 0, st, slab, splits, count, dW, accum);
     if (db) {                                          // f32 mode: separate column-sum pass
-        hipError_t e = launch_colsum((const float*)dY, lddy, M, N1, db_part, db, accum, st);
-        if (e != hipSuccess) return e;
+        for (int c0 = 0; c0 < N1; c0 += COLSUM_MAXC) {  // wide layers (FFN of DynTrans: 2048) in column chunks
+            const int cw = N1 - c0 < COLSUM_MAXC ? N1 - c0 : COLSUM_MAXC;
+            hipError_t e = launch_colsum((const float*)dY + c0, lddy, M, cw, db_part, db + c0, accum, st);
+            if (e != hipSuccess) return e;
+        }
     }
     return hipGetLastError();
 }

@@ -55,11 +55,17 @@ def icecube86_geometry() -> np.ndarray:
 
 
 def synthetic_icecube86_raw(n_events: int, seed: int = 20241016, mean_scale: float = 130.0,
-                            n_min: int = 8, n_max: int = 2000):
-    """Raw (un-standardised) pulses: ``x[N,7]`` float32, ``ptr[B+1]`` int64, ``energy[B]``."""
+                            n_min: int = 8, n_max: int = 2000, count_range: Optional[tuple] = None):
+    """Raw (un-standardised) pulses: ``x[N,7]`` float32, ``ptr[B+1]`` int64, ``energy[B]``.
+    ``count_range=(lo, hi)``: pulses per event log-uniform in [lo, hi] instead of the clipped log-normal
+    (BASELINE configs[3]: "mixed 50-3000 pulses/event")."""
     rng = np.random.default_rng(seed)
     geo = icecube86_geometry()
-    n = np.clip(np.rint(rng.lognormal(np.log(mean_scale), 0.55, n_events)), n_min, n_max).astype(np.int64)
+    if count_range is not None:
+        lo_c, hi_c = count_range
+        n = np.rint(np.exp(rng.uniform(np.log(lo_c), np.log(hi_c), n_events))).astype(np.int64)
+    else:
+        n = np.clip(np.rint(rng.lognormal(np.log(mean_scale), 0.55, n_events)), n_min, n_max).astype(np.int64)
     ptr = np.zeros(n_events + 1, np.int64)
     ptr[1:] = np.cumsum(n)
     x = np.empty((int(ptr[-1]), 7), np.float32)

@@ -1,0 +1,342 @@
+"""graphnet_amd/tito.py — ``DynEdgeTITO`` on the HIP kernels.
+
+Mirrors ``/root/reference/src/graphnet/models/gnn/dynedge_kaggle_tito.py`` (ctor l.32-138, layers l.140-196, forward
+l.236-268) and ``models/components/layers.py:72-197`` (``EdgeConvTito``, ``DynTrans``): same constructor
+arguments, same sub-module names — hence the same state-dict keys, Lightning-checkpoint compatible.
+
+What runs where
+  * ``EdgeConvTito`` (message ``nn([x_i, x_j - x_i, x_j])``, max aggregation, static edges): the per-node split
+    ``W1 [x_i | x_j-x_i | x_j] = (Wa - Wb) x_i + (Wb + Wc) x_j`` turns the first Linear into one MFMA GEMM over
+    nodes; LeakyReLU / second Linear / arg-routed max on the edge-row kernels of ``csrc/generic.hip``.
+  * the transformer encoder layer: in/out projections and the 2048-wide FFN on the MFMA GEMM kernels with fused
+    bias / relu / residual-accumulate epilogues, LayerNorms on the row kernels, and the attention itself on
+    ``csrc/attn.hip`` — ragged, every pulse attends to its own event, no ``to_dense_batch`` padding.
+  * dropout: the reference builds ``TransformerEncoderLayer`` with torch's default ``dropout=0.1``; this backend has
+    no dropout kernel yet and refuses to train with a non-zero rate (``dropout=0.0`` is the constructor default
+    here; inference / eval is identical to the reference either way).
+"""
+from __future__ import annotations
+
+from typing import Any, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+from .gnn import GNN, _ksegs, _maybe
+
+_DT_PARAMS = 18   # tensors per DynTrans layer, see DynTrans.kernel_params
+
+
+def _wt(mode: int, W: Tensor, widths: Sequence[int]) -> Tensor:
+    return ops.pack_weight(W, widths, ops.mode_dtype(mode), ops.gemm_kunit(mode))
+
+
+class _DynTransFunction(torch.autograd.Function):
+    """One ``DynTrans`` layer (``layers.py:117-197``) as a single autograd node."""
+
+    @staticmethod
+    def forward(ctx, cfg: dict, x: Tensor, *p: Tensor) -> Tensor:  # type: ignore[override]
+        (W1, b1, W2, b2, g0, be0, Win, bin_, Wout, bout, Wl1, bl1, Wl2, bl2, g1, be1, g2, be2) = p
+        mode, g, H = cfg["mode"], cfg["graph"], cfg["n_head"]
+        ptr, plan = cfg["ptr"], cfg["plan"]
+        dev = x.device
+        N, Fin = int(x.shape[0]), int(x.shape[1])
+        H1, d = int(W1.shape[0]), int(W2.shape[0])
+        H1p, dr = ops.round_up(H1, 32), ops.round_up(d, 8)
+        if d % 32 or d > 512:
+            raise NotImplementedError("graphnet_amd.DynTrans: d_model must be a multiple of 32, at most 512")
+        xin = torch.zeros((N, ops.round_up(Fin, 32)), dtype=torch.float32, device=dev)
+        xin[:, :Fin] = x
+        # --- EdgeConvTito: P = (Wa - Wb) x + b1, Q = (Wb + Wc) x
+        Wa, Wb, Wc = W1[:, :Fin], W1[:, Fin:2 * Fin], W1[:, 2 * Fin:]
+        Wpq = torch.zeros((2 * H1p, Fin), dtype=torch.float32, device=dev)
+        Wpq[:H1] = Wa - Wb
+        Wpq[H1p:H1p + H1] = Wb + Wc
+        bpq = torch.zeros(2 * H1p, dtype=torch.float32, device=dev)
+        bpq[:H1] = b1
+        PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), _wt(mode, Wpq, [Fin]), 2 * H1p, bias=bpq)
+        ic, jc = ops.edge_rows(g)
+        pre1 = ops.edge_gather_pre(PQ, H1p, ic, jc)
+        a1, _ = ops.rownorm_act_fwd(pre1, H1, "leaky_relu", valid=jc, cpad=H1p)
+        z2 = ops.linear_fwd(mode, [(a1, H1p)], _wt(mode, W2, [H1]), d, bias=b2.contiguous(), out_cols=dr)
+        m, _ = ops.rownorm_act_fwd(z2, d, "leaky_relu", valid=jc, cpad=dr)
+        conv, aux = ops.slot_reduce(m, d, g, "max")
+        residual = Fin == d                                             # layers.py:183-186
+        r = conv.add_(x) if residual else conv
+        y0, st0 = ops.rownorm_act_fwd(r, d, "identity", g0, be0)        # self.norm1
+        # --- TransformerEncoderLayer, norm_first=False
+        qkv = ops.linear_fwd(mode, _ksegs([(y0, d)]), _wt(mode, Win, [d]), 3 * d, bias=bin_.contiguous())
+        att, lse2 = ops.attention_fwd(qkv, H, ptr, plan)
+        z1 = y0.clone()
+        ops.linear_fwd(mode, _ksegs([(att, d)]), _wt(mode, Wout, [d]), d, bias=bout.contiguous(), out=z1, accum=True)
+        y1, st1 = ops.rownorm_act_fwd(z1, d, "identity", g1, be1)
+        F = int(Wl1.shape[0])
+        h = ops.linear_fwd(mode, _ksegs([(y1, d)]), _wt(mode, Wl1, [d]), F, bias=bl1.contiguous(), relu=True)
+        z3 = y1.clone()
+        ops.linear_fwd(mode, _ksegs([(h, F)]), _wt(mode, Wl2, [F]), d, bias=bl2.contiguous(), out=z3, accum=True)
+        y2, st2 = ops.rownorm_act_fwd(z3, d, "identity", g2, be2)
+        ctx.cfg, ctx.p = cfg, p
+        ctx.saved = (xin, Fin, pre1, a1, z2, aux, residual, r, st0, y0, qkv, att, lse2, z1, st1, y1, h, z3, st2)
+        return y2
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):  # type: ignore[override]
+        cfg, p = ctx.cfg, ctx.p
+        (W1, b1, W2, b2, g0, be0, Win, bin_, Wout, bout, Wl1, bl1, Wl2, bl2, g1, be1, g2, be2) = p
+        (xin, Fin, pre1, a1, z2, aux, residual, r, st0, y0, qkv, att, lse2, z1, st1, y1, h, z3, st2) = ctx.saved
+        mode, g, H = cfg["mode"], cfg["graph"], cfg["n_head"]
+        ptr, plan = cfg["ptr"], cfg["plan"]
+        dev = xin.device
+        N = int(xin.shape[0])
+        H1, d, F = int(W1.shape[0]), int(W2.shape[0]), int(Wl1.shape[0])
+        H1p, dr = ops.round_up(H1, 32), ops.round_up(d, 8)
+        grads: List[Optional[Tensor]] = [None] * _DT_PARAMS
+        gy = gy.contiguous().to(torch.float32)
+        # norm2, FFN
+        dz3, grads[16], grads[17] = ops.rownorm_act_bwd(gy, z3, d, "identity", g2, be2, st2)
+        grads[12], grads[13] = ops.linear_wgrad(mode, dz3, d, _ksegs([(h, F)]), with_bias=True)
+        dh = ops.linear_fwd(mode, _ksegs([(dz3, d)]), _wt(mode, Wl2.t(), [d]), F, gate=h)
+        grads[10], grads[11] = ops.linear_wgrad(mode, dh, F, _ksegs([(y1, d)]), with_bias=True)
+        ops.linear_fwd(mode, _ksegs([(dh, F)]), _wt(mode, Wl1.t(), [F]), d, out=dz3, accum=True)      # dy1
+        # norm1, attention
+        dz1, grads[14], grads[15] = ops.rownorm_act_bwd(dz3, z1, d, "identity", g1, be1, st1)
+        grads[8], grads[9] = ops.linear_wgrad(mode, dz1, d, _ksegs([(att, d)]), with_bias=True)
+        datt = ops.linear_fwd(mode, _ksegs([(dz1, d)]), _wt(mode, Wout.t(), [d]), d)
+        dqkv = ops.attention_bwd(qkv, H, ptr, plan, att, lse2, datt)
+        grads[6], grads[7] = ops.linear_wgrad(mode, dqkv, 3 * d, _ksegs([(y0, d)]), with_bias=True)
+        ops.linear_fwd(mode, _ksegs([(dqkv, 3 * d)]), _wt(mode, Win.t(), [3 * d]), d, out=dz1, accum=True)  # dy0
+        # DynTrans.norm1
+        dres, grads[4], grads[5] = ops.rownorm_act_bwd(dz1, r, d, "identity", g0, be0, st0)
+        # EdgeConvTito
+        ic, jc = ops.edge_rows(g)
+        grows = ops.slot_reduce_bwd(dres, d, g, "max", aux, cpad=dr)
+        dz2, _, _ = ops.rownorm_act_bwd(grows, z2, d, "leaky_relu", valid=jc, cpad=dr)
+        dW2, grads[3] = ops.linear_wgrad(mode, dz2, d, [(a1, H1p)], with_bias=True)
+        grads[2] = dW2[:, :H1]
+        da1 = ops.linear_fwd(mode, _ksegs([(dz2, d)]), _wt(mode, W2.t(), [d]), H1, out_cols=H1p)
+        dpre1, _, _ = ops.rownorm_act_bwd(da1, pre1, H1, "leaky_relu", valid=jc, cpad=H1p)
+        dPQ = torch.empty((N, 2 * H1p), dtype=torch.float32, device=dev)
+        dPQ[:, :H1p] = ops.slot_sum(dpre1, H1p, g)
+        ops.edgeconv_dq_gather(ops.MODE_F32, g, dpre1, H1p, dPQ[:, H1p:])
+        dWpq, dbpq = ops.linear_wgrad(mode, dPQ, 2 * H1p, _ksegs([(xin, Fin)]), with_bias=True)
+        dWpq = dWpq[:, :Fin]
+        dWp, dWq = dWpq[:H1], dWpq[H1p:H1p + H1]
+        grads[0] = torch.cat([dWp, dWq - dWp, dWq], dim=1)               # d/dWa, d/dWb, d/dWc
+        grads[1] = dbpq[:H1]
+        dx = None
+        if ctx.needs_input_grad[1]:
+            Wa, Wb, Wc = W1[:, :Fin], W1[:, Fin:2 * Fin], W1[:, 2 * Fin:]
+            WpqT = torch.zeros((Fin, 2 * H1p), dtype=torch.float32, device=dev)
+            WpqT[:, :H1] = (Wa - Wb).t()
+            WpqT[:, H1p:H1p + H1] = (Wb + Wc).t()
+            if residual:        # Fin == d: the residual branch's gradient is the accumulate target
+                dx = ops.linear_fwd(mode, [(dPQ, 2 * H1p)], _wt(mode, WpqT, [2 * H1p]), Fin, out=dres, accum=True)
+            else:
+                dx = ops.linear_fwd(mode, [(dPQ, 2 * H1p)], _wt(mode, WpqT, [2 * H1p]), Fin,
+                                    out_cols=ops.round_up(Fin, 8))[:, :Fin]
+        return (None, dx) + tuple(grads)
+
+
+class _PostPoolFunction(torch.autograd.Function):
+    """Post-processing MLP (Linear + LeakyReLU per layer, ``dynedge_kaggle_tito.py:160-174``) followed by the
+    global pooling (``l.198-212``).  ``params``: W, b per layer."""
+
+    @staticmethod
+    def forward(ctx, cfg: dict, x: Tensor, *params: Tensor) -> Tensor:  # type: ignore[override]
+        mode = cfg["mode"]
+        segs = [(x.contiguous(), int(x.shape[1]))]
+        zs = []
+        for t in range(len(params) // 2):
+            W, b = params[2 * t], params[2 * t + 1]
+            P_ = int(W.shape[0])
+            z = ops.linear_fwd(mode, _ksegs(segs), _wt(mode, W, [segs[0][1]]), P_, bias=b.contiguous(),
+                               out_cols=ops.round_up(P_, 8))
+            y, _ = ops.rownorm_act_fwd(z, P_, "leaky_relu", cpad=ops.round_up(P_, 8))
+            zs.append(z)
+            segs = [(y, P_)]
+        y_last, P = segs[0]
+        ctx.cfg, ctx.params, ctx.x, ctx.zs = cfg, params, x, zs
+        cfg["post"] = y_last[:, :P] if cfg.get("want_trace") else None
+        pooled, ctx.amin, ctx.amax = ops.segment_pool_fwd(y_last, P, cfg["ptr"], cfg["pools"])
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):  # type: ignore[override]
+        cfg, params, x, zs = ctx.cfg, ctx.params, ctx.x, ctx.zs
+        mode = cfg["mode"]
+        N = int(x.shape[0])
+        nl = len(params) // 2
+        P = int(params[-2].shape[0]) if nl else int(x.shape[1])
+        gy = ops.segment_pool_bwd(gout.contiguous().to(torch.float32), P, cfg["ptr"], cfg["batch"], N, cfg["pools"],
+                                  ctx.amin, ctx.amax, None)
+        grads: List[Optional[Tensor]] = [None] * len(params)
+        for t in reversed(range(nl)):
+            W = params[2 * t]
+            Pt, Pin = int(W.shape[0]), int(W.shape[1])
+            dz, _, _ = ops.rownorm_act_bwd(gy.contiguous(), zs[t], Pt, "leaky_relu", cpad=ops.round_up(Pt, 8))
+            if t > 0:
+                yprev, _ = ops.rownorm_act_fwd(zs[t - 1], Pin, "leaky_relu", cpad=ops.round_up(Pin, 8))
+                in_segs = [(yprev, Pin)]
+            else:
+                in_segs = [(x.contiguous(), Pin)]
+            dW, grads[2 * t + 1] = ops.linear_wgrad(mode, dz, Pt, _ksegs(in_segs), with_bias=True)
+            grads[2 * t] = dW[:, :Pin]
+            gy = ops.linear_fwd(mode, _ksegs([(dz, Pt)]), _wt(mode, W.t(), [Pt]), Pin, out_cols=ops.round_up(Pin, 8))
+        return (None, gy[:, :int(x.shape[1])]) + tuple(grads)
+
+
+class DynTrans(torch.nn.Module):
+    """Parameter holder + launcher of one ``DynTrans`` layer; attribute names as in ``layers.py:117-164``."""
+
+    def __init__(self, layer_sizes: Optional[List[int]] = None, aggr: str = "max",
+                 features_subset: Any = None, n_head: int = 8, dropout: float = 0.0, **kwargs: Any):
+        super().__init__()
+        if features_subset is None:
+            features_subset = slice(None)
+        assert isinstance(features_subset, (list, slice))
+        if aggr != "max":
+            raise NotImplementedError("graphnet_amd.DynTrans: aggr must be 'max' (what DynEdgeTITO uses); no fallback")
+        if layer_sizes is None:
+            layer_sizes = [256, 256, 256]
+        if len(layer_sizes) != 3:
+            raise NotImplementedError("graphnet_amd.DynTrans: the edge MLP must have exactly two layers; no fallback")
+        layers: List[torch.nn.Module] = []
+        for ix, (nb_in, nb_out) in enumerate(zip(layer_sizes[:-1], layer_sizes[1:])):
+            if ix == 0:
+                nb_in *= 3
+            layers.append(torch.nn.Linear(nb_in, nb_out))
+            layers.append(torch.nn.LeakyReLU())
+        d_model = layer_sizes[-1]
+        self.nn = torch.nn.Sequential(*layers)
+        self.features_subset = features_subset
+        self.norm1 = torch.nn.LayerNorm(d_model, eps=1e-5)
+        enc = torch.nn.TransformerEncoderLayer(d_model=d_model, nhead=n_head, batch_first=True, norm_first=False,
+                                               dropout=dropout)
+        self._transformer_encoder = torch.nn.TransformerEncoder(enc, num_layers=1)
+        self._n_head = n_head
+        self._dropout = dropout
+
+    def kernel_params(self) -> List[Tensor]:
+        e = self._transformer_encoder.layers[0]
+        sa = e.self_attn
+        return [self.nn[0].weight, self.nn[0].bias, self.nn[2].weight, self.nn[2].bias, self.norm1.weight, self.norm1.bias,
+                sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+                e.linear1.weight, e.linear1.bias, e.linear2.weight, e.linear2.bias,
+                e.norm1.weight, e.norm1.bias, e.norm2.weight, e.norm2.bias]
+
+    def forward(self, x: Tensor, cfg: dict) -> Tensor:
+        if self.training and self._dropout > 0.0:
+            raise NotImplementedError("graphnet_amd.DynTrans has no dropout kernel: construct with dropout=0.0 to "
+                                      "train, or call .eval(); there is no fallback")
+        return _DynTransFunction.apply(dict(cfg, n_head=self._n_head), x, *self.kernel_params())
+
+
+class DynEdgeTITO(GNN):
+    """DynEdgeTITO (dynamical edge convolution with transformer) on MI355X.  Constructor as
+    ``dynedge_kaggle_tito.py:32-59`` plus ``dropout`` (see the module docstring)."""
+
+    def __init__(self, nb_inputs: int, features_subset: Optional[List[int]] = None,
+                 dyntrans_layer_sizes: Optional[List[Tuple[int, ...]]] = None,
+                 global_pooling_schemes: List[str] = ["max"], use_global_features: bool = True,
+                 use_post_processing_layers: bool = True, post_processing_layer_sizes: Optional[List[int]] = None,
+                 readout_layer_sizes: Optional[List[int]] = None, n_head: int = 8, nb_neighbours: int = 8,
+                 dropout: float = 0.0):
+        if dyntrans_layer_sizes is None:
+            dyntrans_layer_sizes = [(256, 256)] * 4
+        assert isinstance(dyntrans_layer_sizes, list) and len(dyntrans_layer_sizes)
+        dyntrans_layer_sizes = [tuple(s) for s in dyntrans_layer_sizes]
+        assert all(len(s) > 0 and all(v > 0 for v in s) for s in dyntrans_layer_sizes)
+        self._dyntrans_layer_sizes = dyntrans_layer_sizes
+        self._post_processing_layer_sizes = post_processing_layer_sizes or [336, 256]
+        self._readout_layer_sizes = readout_layer_sizes or [256, 128]
+        if isinstance(global_pooling_schemes, str):
+            global_pooling_schemes = [global_pooling_schemes]
+        assert global_pooling_schemes, "No global pooling schemes were request, so cannot add global variables after pooling."
+        for s in global_pooling_schemes:
+            assert s in ops.POOL_CODES, f"Global pooling scheme {s} not supported."
+        self._global_pooling_schemes = list(global_pooling_schemes)
+        super().__init__(nb_inputs, self._readout_layer_sizes[-1])
+        self._activation = torch.nn.LeakyReLU()
+        self._nb_inputs = nb_inputs
+        self._nb_global_variables = 5 + nb_inputs
+        self._nb_neighbours = nb_neighbours
+        self._features_subset = features_subset or [0, 1, 2, 3]
+        self._use_global_features = use_global_features
+        self._use_post_processing_layers = use_post_processing_layers
+        self._n_head = n_head
+        self._compute_mode = ops.MODE_BF16
+        self._knn_strict = False
+        self._graph_columns = [0, 1, 2]
+        # layers (dynedge_kaggle_tito.py:140-196)
+        self._conv_layers = torch.nn.ModuleList()
+        lat = nb_inputs
+        for sizes in dyntrans_layer_sizes:
+            self._conv_layers.append(DynTrans([lat] + list(sizes), aggr="max", features_subset=self._features_subset,
+                                              n_head=n_head, dropout=dropout))
+            lat = sizes[-1]
+        if use_post_processing_layers:
+            mods: List[torch.nn.Module] = []
+            ls = [lat] + list(self._post_processing_layer_sizes)
+            for a, b in zip(ls[:-1], ls[1:]):
+                mods += [torch.nn.Linear(a, b), self._activation]
+            self._post_processing = torch.nn.Sequential(*mods)
+            lat = ls[-1]
+        lat = lat * len(self._global_pooling_schemes) + (self._nb_global_variables if use_global_features else 0)
+        mods = []
+        ls = [lat] + list(self._readout_layer_sizes)
+        for a, b in zip(ls[:-1], ls[1:]):
+            mods += [torch.nn.Linear(a, b), self._activation]
+        self._readout = torch.nn.Sequential(*mods)
+
+    def set_backend(self, *, dtype: str = "bf16", knn_mode: str = "compat",
+                    graph_columns: Optional[Sequence[int]] = None) -> "DynEdgeTITO":
+        """``dtype``: "fp32" (exact-f32 MFMA, parity mode) or "bf16" (bf16 MFMA operands, fp32 accumulate and
+        storage).  ``graph_columns``: coordinates of the k-NN built on device when the batch has no edges."""
+        self._compute_mode = {"fp32": ops.MODE_F32, "bf16": ops.MODE_BF16}[dtype]
+        self._knn_strict = {"compat": False, "strict": True}[knn_mode]
+        if graph_columns is not None:
+            self._graph_columns = list(graph_columns)
+        return self
+
+    def forward(self, data: Any, return_trace: bool = False) -> Tensor:
+        """Apply learnable forward pass (``dynedge_kaggle_tito.py:236-268``)."""
+        x = data.x
+        if not x.is_cuda:
+            raise RuntimeError("graphnet_amd.DynEdgeTITO runs on an MI355X (HIP) device only; move the batch to 'cuda'.")
+        x = x.to(torch.float32)
+        N = int(x.shape[0])
+        n_pulses = data.n_pulses.to(torch.int32)
+        ptr = _maybe(data, "ptr")
+        if ptr is None:
+            ptr = torch.zeros(n_pulses.shape[0] + 1, dtype=torch.int64, device=x.device)
+            ptr[1:] = torch.cumsum(torch.bincount(data.batch, minlength=n_pulses.shape[0]), 0)
+        ptr32 = ptr.to(torch.int32)
+        batch = _maybe(data, "batch")
+        batch32 = batch.to(torch.int32) if batch is not None else ops.ptr_to_batch(ptr32, N)
+        table = _maybe(data, "nbr_table")
+        if not isinstance(table, ops.NeighbourTable):
+            ei = _maybe(data, "edge_index")
+            table = ops.table_from_edge_index(ei, N, self._nb_neighbours) if ei is not None else \
+                ops.knn_graph(x, self._graph_columns, batch32, ptr32, self._nb_neighbours, strict=self._knn_strict)
+        plan = ops.knn_plan(ptr32, N)
+        gv = ops.graph_globals(x, ptr32, table, n_pulses) if self._use_global_features else None
+        cfg = {"mode": self._compute_mode, "graph": table, "ptr": ptr32, "batch": batch32, "plan": plan}
+        conv_out = []
+        for conv in self._conv_layers:
+            x = conv(x, cfg)
+            conv_out.append(x)
+        pcfg = {"mode": self._compute_mode, "ptr": ptr32, "batch": batch32, "pools": self._global_pooling_schemes,
+                "want_trace": return_trace}
+        post_params: List[Tensor] = []
+        if self._use_post_processing_layers:
+            for m in self._post_processing:
+                if isinstance(m, torch.nn.Linear):
+                    post_params += [m.weight, m.bias]
+        pooled = _PostPoolFunction.apply(pcfg, x, *post_params)
+        out = torch.cat([pooled, gv], dim=1) if self._use_global_features else pooled
+        out = self._readout(out)
+        if return_trace:
+            return out, {"conv_out": conv_out, "post": pcfg.get("post"), "pooled": pooled, "global_variables": gv,
+                         "graph": table}
+        return out

@@ -67,3 +67,64 @@ def test_ragged_attention_rejects_unsupported_head_width():
     plan = ops.knn_plan(ptr_d, 4)
     with pytest.raises(RuntimeError, match="head width"):
         ops.attention_fwd(torch.zeros(4, 3 * 24, device=DEV), 2, ptr_d, plan)
+
+
+def norm_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _tito_pair(name, seed=11, **kw):
+    import graphnet_amd as g
+    from oracle import tito_oracle
+    torch.manual_seed(seed)
+    ref = tito_oracle.DynEdgeTITOOracle(7, **kw).eval()
+    m = g.DynEdgeTITO(7, **kw)
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).set_backend(dtype=name)
+    return m, ref
+
+
+@pytest.mark.parametrize("name,mode,tol", [("fp32", 0, 1e-4), ("bf16", 1, 3e-2)])
+def test_dynedge_tito_forward_backward(oracle, name, mode, tol):
+    """DynEdgeTITO (dynedge_kaggle_tito.py:236-268): two DynTrans layers (first without, second with the residual),
+    post MLP, max + mean pooling, globals, read-out.  Output, per-layer activations and every gradient (edge
+    MLP, LayerNorms, attention in/out projections, FFN, post MLP, read-out) against the oracle on the same edges."""
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    b = synthetic_icecube86_batch(7, seed=17)
+    b.x[3:16, :3] = b.x[2, :3]          # duplicate positions: overflow rows in the neighbour table
+    kw = dict(dyntrans_layer_sizes=[(64, 64), (64, 64)], post_processing_layer_sizes=[48, 32],
+              readout_layer_sizes=[32, 16], global_pooling_schemes=["max", "mean"], n_head=4)
+    m, ref = _tito_pair(name, **kw)
+    ei = oracle.knn_graph(b.x, 8, b.batch, [0, 1, 2])
+    yo, tro = ref(b.x, ei, b.batch, b.n_pulses, return_trace=True)
+    w = torch.randn(yo.shape, generator=torch.Generator().manual_seed(2))
+    (yo * w).sum().backward()
+    m.train()
+    y, tr = m(b.to(DEV), return_trace=True)
+    (y * w.to(DEV)).sum().backward()
+    assert torch.equal(tr["graph"].edge_index().cpu(), ei)           # device-built layer-1 graph, bit-exact
+    for l, (a, ao) in enumerate(zip(tr["conv_out"], tro["conv_out"])):
+        assert rel_err(a, ao.detach()) < tol, f"{name}: DynTrans layer {l}"
+    assert rel_err(y, yo.detach()) < tol
+    for (kn, p), (_, po) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, kn
+        if mode == 0:
+            assert rel_err(p.grad, po.grad) < 2e-3, f"{name}: grad {kn}"
+        else:   # bf16 operands: leaky-relu / relu / max-arg decisions of single elements may flip, and the rounding
+            # passes two softmaxes and six LayerNorms before it reaches the first layer's weights -> Frobenius norm
+            # gate; worst observed 8.1e-2 (first layer's FFN weight), typical 1e-2
+            assert norm_err(p.grad, po.grad) < 1.2e-1, f"{name}: grad {kn}"
+
+
+def test_dynedge_tito_state_dict_and_dropout_guard():
+    import graphnet_amd as g
+    from oracle import tito_oracle
+    kw = dict(dyntrans_layer_sizes=[(32, 32)], post_processing_layer_sizes=[32], readout_layer_sizes=[16], n_head=4)
+    assert list(g.DynEdgeTITO(7, **kw).state_dict()) == list(tito_oracle.DynEdgeTITOOracle(7, **kw).state_dict())
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    b = synthetic_icecube86_batch(3, seed=1).to(DEV)
+    m = g.DynEdgeTITO(7, dropout=0.1, **kw).to(DEV)
+    with pytest.raises(NotImplementedError, match="dropout"):
+        m.train()(b)
+    assert m.eval()(b).shape == (3, 16)
