@@ -584,7 +584,7 @@ def segment_pool_bwd(gout: Tensor, C: int, ptr: Tensor, batch: Tensor, N: int, s
 
 
 # ------------------------------------------------------------------------------ ragged self attention (DynTrans)
-def attention_fwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor):
+def attention_fwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, mode: int = MODE_F32):
     """``softmax(Q K^T / sqrt(dh)) V`` per head, every pulse attending to its own event (``gn_attention_fwd``).
     ``qkv`` fp32 ``[N, 3 d]`` (Q | K | V); ``plan`` from :func:`knn_plan`.  -> (out [N, d], lse2 [N, H])."""
     _need(qkv, torch.float32, "qkv")
@@ -596,12 +596,13 @@ def attention_fwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor):
     out = torch.empty((N, d), dtype=torch.float32, device=qkv.device)
     lse2 = torch.empty((N, n_head), dtype=torch.float32, device=qkv.device)
     with _timed("attention_fwd"):
-        _lib.check(_lib.lib().gn_attention_fwd(_p(qkv), _rows(qkv, "qkv"), n_head, d // n_head, _p(ptr), _p(plan), B, N,
+        _lib.check(_lib.lib().gn_attention_fwd(mode, _p(qkv), _rows(qkv, "qkv"), n_head, d // n_head, _p(ptr), _p(plan), B, N,
                                                _p(out), d, _p(lse2), _st()))
     return out, lse2
 
 
-def attention_bwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, out: Tensor, lse2: Tensor, dout: Tensor) -> Tensor:
+def attention_bwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, out: Tensor, lse2: Tensor, dout: Tensor,
+                  mode: int = MODE_F32) -> Tensor:
     """Gradient of :func:`attention_fwd` w.r.t. ``qkv`` -> [N, 3 d] fp32."""
     _need(qkv, torch.float32, "qkv"); _need(dout, torch.float32, "dout"); _need(out, torch.float32, "out")
     N, d3 = int(qkv.shape[0]), int(qkv.shape[1])
@@ -610,7 +611,7 @@ def attention_bwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, out: Tens
     dqkv = torch.empty((N, d3), dtype=torch.float32, device=qkv.device)
     delta = torch.empty((N, n_head), dtype=torch.float32, device=qkv.device)
     with _timed("attention_bwd"):
-        _lib.check(_lib.lib().gn_attention_bwd(_p(qkv), _rows(qkv, "qkv"), n_head, d // n_head, _p(ptr), _p(plan), B, N,
+        _lib.check(_lib.lib().gn_attention_bwd(mode, _p(qkv), _rows(qkv, "qkv"), n_head, d // n_head, _p(ptr), _p(plan), B, N,
                                                _p(out), _rows(out, "out"), _p(dout), _rows(dout, "dout"), _p(lse2),
                                                _p(delta), _p(dqkv), d3, _st()))
     return dqkv

@@ -214,10 +214,12 @@ int gn_segment_pool_bwd(const float* gout, int32_t C, const int32_t* ptr, const 
  * pulses of its own event (ptr), nothing is padded.  qkv[N, ld] fp32 = [Q | K | V], each H*DH wide (the in_proj
  * output); tile_ptr from gn_knn_plan; out[N, ldo] = softmax(Q K^T / sqrt(DH)) V per head, heads side by side;
  * lse2[N, H] = log2 of the softmax denominators (saved for the backward).  gn_attention_bwd: dqkv[N, lddq] =
- * gradient w.r.t. qkv given dout; delta[N, H] is scratch.  DH in {8, 16, 32, 64}. */
-int gn_attention_fwd(const float* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr, const int32_t* tile_ptr,
+ * gradient w.r.t. qkv given dout; delta[N, H] is scratch.  DH in {8, 16, 32, 64}.  mode 0: exact fp32 on the
+ * vector ALU; mode 1: bf16 operands on the matrix core for DH in {32, 64} (fp32 softmax statistics and
+ * accumulation), the fp32 kernels otherwise. */
+int gn_attention_fwd(int32_t mode, const float* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr, const int32_t* tile_ptr,
                      int32_t B, int32_t N, float* out, int64_t ldo, float* lse2, void* stream);
-int gn_attention_bwd(const float* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr, const int32_t* tile_ptr,
+int gn_attention_bwd(int32_t mode, const float* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr, const int32_t* tile_ptr,
                      int32_t B, int32_t N, const float* out, int64_t ldo, const float* dout, int64_t lddo,
                      const float* lse2, float* delta, float* dqkv, int64_t lddq, void* stream);
 

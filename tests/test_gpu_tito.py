@@ -18,6 +18,11 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def norm_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
 def _ragged_attention_reference(qkv: torch.Tensor, ptr, H: int) -> torch.Tensor:
     """fp64 restatement of the attention core of ``tito_oracle.self_attention_ragged`` (no projections)."""
     N, d3 = qkv.shape
@@ -59,6 +64,15 @@ def test_ragged_attention_forward_backward(H, dh):
     dqkv = ops.attention_bwd(x, H, ptr_d, plan, out, lse2, w.float().to(DEV))
     for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
         assert rel_err(dqkv[:, sl], qkv.grad[:, sl]) < 2e-5, name
+    # mode 1: bf16 operands on the matrix core for head widths 32 / 64 (the fp32 kernels again otherwise);
+    # Q, K, V, P and dS are rounded to bf16 (2^-9 relative), softmax statistics and accumulation stay fp32
+    out1, lse1 = ops.attention_fwd(x, H, ptr_d, plan, ops.MODE_BF16)
+    assert rel_err(out1, want.detach()) < 2e-2
+    assert rel_err(lse1, lse2) < 2e-2
+    dqkv1 = ops.attention_bwd(x, H, ptr_d, plan, out1, lse1, w.float().to(DEV), ops.MODE_BF16)
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        assert rel_err(dqkv1[:, sl], qkv.grad[:, sl]) < 3e-2, name
+        assert norm_err(dqkv1[:, sl], qkv.grad[:, sl]) < 1e-2, name
 
 
 def test_ragged_attention_rejects_unsupported_head_width():
@@ -67,11 +81,6 @@ def test_ragged_attention_rejects_unsupported_head_width():
     plan = ops.knn_plan(ptr_d, 4)
     with pytest.raises(RuntimeError, match="head width"):
         ops.attention_fwd(torch.zeros(4, 3 * 24, device=DEV), 2, ptr_d, plan)
-
-
-def norm_err(a: torch.Tensor, b: torch.Tensor) -> float:
-    a, b = a.double().cpu(), b.double().cpu()
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
 def _tito_pair(name, seed=11, **kw):
