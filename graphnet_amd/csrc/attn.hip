@@ -274,30 +274,33 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(
 }
 
 
-// ================================================================================ bf16 MFMA kernels (mode 1)
-// One wave = 32 queries (forward, dQ pass) or 32 keys (dK/dV pass), head width DH = 32*NB.  Every product is
-// formed TRANSPOSED so that the quantity a softmax row needs is a per-lane scalar:
+// ================================================================================ bf16 MFMA kernels
+// bf16 in HBM (qkv, out, dout, dqkv), fp32 softmax statistics and accumulation.  One wave = one 64-row tile of the
+// plan = two groups of 32 queries (forward, dQ pass) or 32 keys (dK/dV pass); head width DH = 32*NB.  Every
+// product is formed TRANSPOSED so that what a softmax row needs is a per-lane scalar:
 //   S^T[key][query] = K Q^T   -> accumulator column = lane&31 = query; a lane's 16 registers (+ the other half
 //                                wave's 16) are the keys of ITS query: max / sum / rescale are in-lane,
 //   O^T[d][query]  += V^T P^T -> P^T leaves the S^T accumulators already in B-operand layout (registers 8t..8t+7
 //                                of lane-half h are keys 16t+4h+{0..3, 8..11}); V^T fragments with the same key
-//                                order come out of a row-major LDS tile through ds_read_b64_tr_b16.
-// No fragment ever crosses lanes except one xor-32 exchange of the running maximum per block.
+//                                order come out of a row-major LDS tile through ds_read_b64_tr_b16 and serve
+//                                both query groups.
+// No value crosses lanes except one xor-32 exchange of the running maximum per block.  The next block's K / V
+// rows are requested before the current block is computed (one block of prefetch in registers).
 typedef short s16x4_a __attribute__((ext_vector_type(4)));
 typedef short s16x8_a __attribute__((ext_vector_type(8)));
 typedef float f32x8_a __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4_a lds_s16x4_a;
 __host__ __device__ constexpr int attn_tr_pitch(int row_bytes) { return row_bytes + ((64 - row_bytes % 256) + 256) % 256; }
 
-__device__ __forceinline__ bf16x8 attn_load8(const float* __restrict__ p, float mul) {
-    const float4 a = *reinterpret_cast<const float4*>(p);
-    const float4 b = *reinterpret_cast<const float4*>(p + 4);
-    const f32x8_a v = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, b.x * mul, b.y * mul, b.z * mul, b.w * mul};
-    return __builtin_convertvector(v, bf16x8);
-}
+__device__ __forceinline__ bf16x8 attn_ld8(const __bf16* __restrict__ p) { return *reinterpret_cast<const bf16x8*>(p); }
 __device__ __forceinline__ bf16x8 attn_pack8(const f32x16& v, int t) {
     const f32x8_a w = {v[8 * t], v[8 * t + 1], v[8 * t + 2], v[8 * t + 3], v[8 * t + 4], v[8 * t + 5], v[8 * t + 6], v[8 * t + 7]};
     return __builtin_convertvector(w, bf16x8);
+}
+__device__ __forceinline__ void attn_store4(__bf16* p, float a, float b, float c, float d) {
+    bf16x4 v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+    *reinterpret_cast<bf16x4*>(p) = v;
 }
 // A-operand fragment (M = 32 tile columns starting at col0, k = the 16 tile rows {16t + 4h + 0..3, 16t + 4h + 8..11})
 __device__ __forceinline__ bf16x8 attn_tr_frag(const unsigned char* tile, int pitch, int t, int col0, int lane) {
@@ -311,199 +314,261 @@ __device__ __forceinline__ bf16x8 attn_tr_frag(const unsigned char* tile, int pi
 
 template <int NB>
 __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(
-    const float* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
-    int B, float scale2, float* __restrict__ out, long long ldo, float* __restrict__ lse2) {
+    const __bf16* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
+    int B, float scale2, __bf16* __restrict__ out, long long ldo, float* __restrict__ lse2) {
     constexpr int DH = 32 * NB, KS = DH / 16, VP = attn_tr_pitch(DH * 2);
     __shared__ __attribute__((aligned(16))) unsigned char Vs[32 * VP];
-    const int tile = blockIdx.x >> 1, half = blockIdx.x & 1, head = blockIdx.y, lane = threadIdx.x;
+    const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     if (tile >= tile_ptr[B]) return;
     const int e = attn_event_of_tile(tile_ptr, B, tile);
     const int kbeg = ptr[e], kend = ptr[e + 1];
-    const int q0 = kbeg + (tile - tile_ptr[e]) * ATT_TILE + 32 * half;
-    if (q0 >= kend) return;
+    const int q0 = kbeg + (tile - tile_ptr[e]) * ATT_TILE;
     const int E = H * DH, c = lane & 31, h = lane >> 5;
-    const int qi = q0 + c;
-    const int qrow = min(qi, kend - 1);
-    bf16x8 qf[KS];
+    bf16x8 qf[2][KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = attn_load8(qkv + (long long)qrow * ld + head * DH + 16 * s + 8 * h, scale2);
-    f32x16 o[NB];
+    for (int g = 0; g < 2; ++g) {
+        const int qrow = min(q0 + 32 * g + c, kend - 1);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) zero_acc(o[nb]);
-    float m = -INFINITY, l = 0.0f;
+        for (int s = 0; s < KS; ++s) qf[g][s] = attn_ld8(qkv + (long long)qrow * ld + head * DH + 16 * s + 8 * h);
+    }
+    f32x16 o[2][NB];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) zero_acc(o[g][nb]);
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.0f, 0.0f};
+    bf16x8 kn[KS], vn[KS];
+    {
+        const __bf16* kp = qkv + (long long)min(kbeg + c, kend - 1) * ld + E + head * DH;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { kn[s] = attn_ld8(kp + 16 * s + 8 * h); vn[s] = attn_ld8(kp + E + h * (DH / 2) + 8 * s); }
+    }
     for (int kt = kbeg; kt < kend; kt += 32) {
-        const int krow = min(kt + c, kend - 1);
-        const float* kp = qkv + (long long)krow * ld + E + head * DH;
-        bf16x8 kf[KS];
+        bf16x8 kf[KS], vv[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) kf[s] = attn_load8(kp + 16 * s + 8 * h, 1.0f);
-        bf16x8 vv[DH / 16];
+        for (int s = 0; s < KS; ++s) { kf[s] = kn[s]; vv[s] = vn[s]; }
+        {
+            const __bf16* kp = qkv + (long long)min(kt + 32 + c, kend - 1) * ld + E + head * DH;
 #pragma unroll
-        for (int j = 0; j < DH / 16; ++j) vv[j] = attn_load8(kp + E + h * (DH / 2) + 8 * j, 1.0f);
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < DH / 16; ++j)
-            *reinterpret_cast<bf16x8*>(&Vs[c * VP + (h * (DH / 2) + 8 * j) * 2]) = vv[j];
-        __syncthreads();
-        f32x16 s;
-        zero_acc(s);
-#pragma unroll
-        for (int t = 0; t < KS; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qf[t], s, 0, 0, 0);
-        if (kt + 32 > kend) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (kt + acc_row(r, h) >= kend) s[r] = -INFINITY;
+            for (int s = 0; s < KS; ++s) { kn[s] = attn_ld8(kp + 16 * s + 8 * h); vn[s] = attn_ld8(kp + E + h * (DH / 2) + 8 * s); }
         }
-        float mx = s[0];
+        __syncthreads();
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mn = fmaxf(m, mx);
-        const float corr = exp2f(m - mn);
-        float ps = 0.0f;
+        for (int s = 0; s < KS; ++s) *reinterpret_cast<bf16x8*>(&Vs[c * VP + (h * (DH / 2) + 8 * s) * 2]) = vv[s];
+        __syncthreads();
+        const bool tail = kt + 32 > kend;
+        bf16x8 pf[2][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - mn); ps += s[r]; }
-        l = l * corr + ps;
-        m = mn;
+        for (int g = 0; g < 2; ++g) {
+            f32x16 s;
+            zero_acc(s);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+            for (int t = 0; t < KS; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qf[g][t], s, 0, 0, 0);
+            if (tail) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[nb][r] *= corr;
+                for (int r = 0; r < 16; ++r)
+                    if (kt + acc_row(r, h) >= kend) s[r] = -INFINITY;
+            }
+            float mx = s[0];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bf16x8 pf = attn_pack8(s, t);
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m[g], mx * scale2);
+            const float corr = exp2f(m[g] - mn);
+            float ps = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = exp2f(fmaf(s[r], scale2, -mn)); ps += s[r]; }
+            l[g] = l[g] * corr + ps;
+            m[g] = mn;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_tr_frag(Vs, VP, t, nb * 32, lane), pf, o[nb], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[g][nb][r] *= corr;
+            pf[g][0] = attn_pack8(s, 0);
+            pf[g][1] = attn_pack8(s, 1);
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bf16x8 vt = attn_tr_frag(Vs, VP, t, nb * 32, lane);
+                o[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt, pf[0][t], o[0][nb], 0, 0, 0);
+                o[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt, pf[1][t], o[1][nb], 0, 0, 0);
+            }
     }
-    l += __shfl_xor(l, 32);
-    if (qi < kend) {
-        const float inv = 1.0f / l;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+    for (int g = 0; g < 2; ++g) {
+        const int qi = q0 + 32 * g + c;
+        const float lt = l[g] + __shfl_xor(l[g], 32);
+        if (qi < kend) {
+            const float inv = 1.0f / lt;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(out + (long long)qi * ldo + head * DH + nb * 32 + 8 * g + 4 * h) =
-                    make_float4(o[nb][4 * g] * inv, o[nb][4 * g + 1] * inv, o[nb][4 * g + 2] * inv, o[nb][4 * g + 3] * inv);
-        if (h == 0) lse2[(long long)qi * H + head] = m + log2f(l);
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    attn_store4(out + (long long)qi * ldo + head * DH + nb * 32 + 8 * j + 4 * h, o[g][nb][4 * j] * inv,
+                                o[g][nb][4 * j + 1] * inv, o[g][nb][4 * j + 2] * inv, o[g][nb][4 * j + 3] * inv);
+            if (h == 0) lse2[(long long)qi * H + head] = m[g] + log2f(lt);
+        }
     }
 }
 
 template <int NB>
 __global__ __launch_bounds__(64) void attn_bwd_dq_mfma_kernel(
-    const float* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
-    int B, float scale, const float* __restrict__ out, long long ldo, const float* __restrict__ dout, long long lddo,
-    const float* __restrict__ lse2, float* __restrict__ delta, float* __restrict__ dqkv, long long lddq) {
+    const __bf16* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
+    int B, float scale, const __bf16* __restrict__ out, long long ldo, const __bf16* __restrict__ dout, long long lddo,
+    const float* __restrict__ lse2, float* __restrict__ delta, __bf16* __restrict__ dqkv, long long lddq) {
     constexpr int DH = 32 * NB, KS = DH / 16, VP = attn_tr_pitch(DH * 2);
     __shared__ __attribute__((aligned(16))) unsigned char Ks[32 * VP];
-    const int tile = blockIdx.x >> 1, half = blockIdx.x & 1, head = blockIdx.y, lane = threadIdx.x;
+    const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     if (tile >= tile_ptr[B]) return;
     const int e = attn_event_of_tile(tile_ptr, B, tile);
     const int kbeg = ptr[e], kend = ptr[e + 1];
-    const int q0 = kbeg + (tile - tile_ptr[e]) * ATT_TILE + 32 * half;
-    if (q0 >= kend) return;
+    const int q0 = kbeg + (tile - tile_ptr[e]) * ATT_TILE;
     const int E = H * DH, c = lane & 31, h = lane >> 5;
-    const int qi = q0 + c;
-    const int qrow = min(qi, kend - 1);
     const float scale2 = scale * LOG2E;
-    bf16x8 qf[KS], gf[KS];
-    float dl = 0.0f;
+    bf16x8 qf[2][KS], gf[2][KS];
+    float dl[2], ls[2];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        qf[s] = attn_load8(qkv + (long long)qrow * ld + head * DH + 16 * s + 8 * h, scale2);
-        const float* gp = dout + (long long)qrow * lddo + head * DH + 16 * s + 8 * h;
-        const float* op = out + (long long)qrow * ldo + head * DH + 16 * s + 8 * h;
-        gf[s] = attn_load8(gp, 1.0f);
+    for (int g = 0; g < 2; ++g) {
+        const int qrow = min(q0 + 32 * g + c, kend - 1);
+        float d_ = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dl = fmaf(gp[j], op[j], dl);
+        for (int s = 0; s < KS; ++s) {
+            qf[g][s] = attn_ld8(qkv + (long long)qrow * ld + head * DH + 16 * s + 8 * h);
+            gf[g][s] = attn_ld8(dout + (long long)qrow * lddo + head * DH + 16 * s + 8 * h);
+            const bf16x8 ov = attn_ld8(out + (long long)qrow * ldo + head * DH + 16 * s + 8 * h);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d_ = fmaf((float)gf[g][s][j], (float)ov[j], d_);
+        }
+        dl[g] = d_ + __shfl_xor(d_, 32);
+        ls[g] = lse2[(long long)qrow * H + head];
     }
-    dl += __shfl_xor(dl, 32);
-    const float ls = lse2[(long long)qrow * H + head];
-    f32x16 dq[NB];
+    f32x16 dq[2][NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) zero_acc(dq[nb]);
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) zero_acc(dq[g][nb]);
+    bf16x8 kn[KS], vn[KS];
+    {
+        const __bf16* kp = qkv + (long long)min(kbeg + c, kend - 1) * ld + E + head * DH;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { kn[s] = attn_ld8(kp + 16 * s + 8 * h); vn[s] = attn_ld8(kp + E + 16 * s + 8 * h); }
+    }
     for (int kt = kbeg; kt < kend; kt += 32) {
-        const int krow = min(kt + c, kend - 1);
-        const float* kp = qkv + (long long)krow * ld + E + head * DH;
         bf16x8 kf[KS], vf[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) { kf[s] = attn_load8(kp + 16 * s + 8 * h, 1.0f); vf[s] = attn_load8(kp + E + 16 * s + 8 * h, 1.0f); }
+        for (int s = 0; s < KS; ++s) { kf[s] = kn[s]; vf[s] = vn[s]; }
+        {
+            const __bf16* kp = qkv + (long long)min(kt + 32 + c, kend - 1) * ld + E + head * DH;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { kn[s] = attn_ld8(kp + 16 * s + 8 * h); vn[s] = attn_ld8(kp + E + 16 * s + 8 * h); }
+        }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < KS; ++s) *reinterpret_cast<bf16x8*>(&Ks[c * VP + (16 * s + 8 * h) * 2]) = kf[s];
         __syncthreads();
-        f32x16 s, dp;
-        zero_acc(s); zero_acc(dp);
-#pragma unroll
-        for (int t = 0; t < KS; ++t) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qf[t], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t], gf[t], dp, 0, 0, 0);
-        }
         const bool tail = kt + 32 > kend;
+        bf16x8 df[2][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float p = exp2f(s[r] - ls);
-            if (tail && kt + acc_row(r, h) >= kend) p = 0.0f;
-            s[r] = p * (dp[r] - dl);
+        for (int g = 0; g < 2; ++g) {
+            f32x16 s, dp;
+            zero_acc(s); zero_acc(dp);
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qf[g][t], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t], gf[g][t], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = exp2f(fmaf(s[r], scale2, -ls[g]));
+                if (tail && kt + acc_row(r, h) >= kend) p = 0.0f;
+                s[r] = p * (dp[r] - dl[g]);
+            }
+            df[g][0] = attn_pack8(s, 0);
+            df[g][1] = attn_pack8(s, 1);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bf16x8 df = attn_pack8(s, t);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bf16x8 ktf = attn_tr_frag(Ks, VP, t, nb * 32, lane);
+                dq[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, df[0][t], dq[0][nb], 0, 0, 0);
+                dq[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, df[1][t], dq[1][nb], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qi = q0 + 32 * g + c;
+        if (qi < kend) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_tr_frag(Ks, VP, t, nb * 32, lane), df, dq[nb], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    attn_store4(dqkv + (long long)qi * lddq + head * DH + nb * 32 + 8 * j + 4 * h, dq[g][nb][4 * j] * scale,
+                                dq[g][nb][4 * j + 1] * scale, dq[g][nb][4 * j + 2] * scale, dq[g][nb][4 * j + 3] * scale);
+            if (h == 0) delta[(long long)qi * H + head] = dl[g];
         }
-    }
-    if (qi < kend) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(dqkv + (long long)qi * lddq + head * DH + nb * 32 + 8 * g + 4 * h) =
-                    make_float4(dq[nb][4 * g] * scale, dq[nb][4 * g + 1] * scale, dq[nb][4 * g + 2] * scale, dq[nb][4 * g + 3] * scale);
-        if (h == 0) delta[(long long)qi * H + head] = dl;
     }
 }
 
 template <int NB>
 __global__ __launch_bounds__(64) void attn_bwd_dkv_mfma_kernel(
-    const float* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
-    int B, float scale, const float* __restrict__ dout, long long lddo, const float* __restrict__ lse2,
-    const float* __restrict__ delta, float* __restrict__ dqkv, long long lddq) {
+    const __bf16* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
+    int B, float scale, const __bf16* __restrict__ dout, long long lddo, const float* __restrict__ lse2,
+    const float* __restrict__ delta, __bf16* __restrict__ dqkv, long long lddq) {
     constexpr int DH = 32 * NB, KS = DH / 16, VP = attn_tr_pitch(DH * 2);
     __shared__ __attribute__((aligned(16))) unsigned char Qs[32 * VP];
     __shared__ __attribute__((aligned(16))) unsigned char Gs[32 * VP];
     __shared__ __attribute__((aligned(16))) float Ls[32];
     __shared__ __attribute__((aligned(16))) float Ds[32];
-    const int tile = blockIdx.x >> 1, half = blockIdx.x & 1, head = blockIdx.y, lane = threadIdx.x;
+    const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     if (tile >= tile_ptr[B]) return;
     const int e = attn_event_of_tile(tile_ptr, B, tile);
     const int kbeg = ptr[e], kend = ptr[e + 1];
-    const int k0 = kbeg + (tile - tile_ptr[e]) * ATT_TILE + 32 * half;
-    if (k0 >= kend) return;
+    const int k0 = kbeg + (tile - tile_ptr[e]) * ATT_TILE;
     const int E = H * DH, c = lane & 31, h = lane >> 5;
-    const int kj = k0 + c;
-    const int krow = min(kj, kend - 1);
     const float scale2 = scale * LOG2E;
-    bf16x8 kf[KS], vf[KS];
+    bf16x8 kf[2][KS], vf[2][KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        kf[s] = attn_load8(qkv + (long long)krow * ld + E + head * DH + 16 * s + 8 * h, scale2);
-        vf[s] = attn_load8(qkv + (long long)krow * ld + 2 * E + head * DH + 16 * s + 8 * h, 1.0f);
-    }
-    f32x16 dk[NB], dv[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) { zero_acc(dk[nb]); zero_acc(dv[nb]); }
-    for (int qt = kbeg; qt < kend; qt += 32) {
-        const int qrow = min(qt + c, kend - 1);
-        bf16x8 qa[KS], ga[KS];
+    for (int g = 0; g < 2; ++g) {
+        const int krow = min(k0 + 32 * g + c, kend - 1);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            qa[s] = attn_load8(qkv + (long long)qrow * ld + head * DH + 16 * s + 8 * h, 1.0f);
-            ga[s] = attn_load8(dout + (long long)qrow * lddo + head * DH + 16 * s + 8 * h, 1.0f);
+            kf[g][s] = attn_ld8(qkv + (long long)krow * ld + E + head * DH + 16 * s + 8 * h);
+            vf[g][s] = attn_ld8(qkv + (long long)krow * ld + 2 * E + head * DH + 16 * s + 8 * h);
         }
-        const float lv = lse2[(long long)qrow * H + head], dvv = delta[(long long)qrow * H + head];
+    }
+    f32x16 dk[2][NB], dv[2][NB];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { zero_acc(dk[g][nb]); zero_acc(dv[g][nb]); }
+    bf16x8 qn[KS], gn_[KS];
+    float ln, dn;
+    {
+        const int qrow = min(kbeg + c, kend - 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qn[s] = attn_ld8(qkv + (long long)qrow * ld + head * DH + 16 * s + 8 * h);
+            gn_[s] = attn_ld8(dout + (long long)qrow * lddo + head * DH + 16 * s + 8 * h);
+        }
+        ln = lse2[(long long)qrow * H + head]; dn = delta[(long long)qrow * H + head];
+    }
+    for (int qt = kbeg; qt < kend; qt += 32) {
+        bf16x8 qa[KS], ga[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { qa[s] = qn[s]; ga[s] = gn_[s]; }
+        const float lv = ln, dvv = dn;
+        {
+            const int qrow = min(qt + 32 + c, kend - 1);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                qn[s] = attn_ld8(qkv + (long long)qrow * ld + head * DH + 16 * s + 8 * h);
+                gn_[s] = attn_ld8(dout + (long long)qrow * lddo + head * DH + 16 * s + 8 * h);
+            }
+            ln = lse2[(long long)qrow * H + head]; dn = delta[(long long)qrow * H + head];
+        }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -512,49 +577,61 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_mfma_kernel(
         }
         if (h == 0) { Ls[c] = lv; Ds[c] = dvv; }
         __syncthreads();
-        f32x16 s, dp;
-        zero_acc(s); zero_acc(dp);
-#pragma unroll
-        for (int t = 0; t < KS; ++t) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[t], kf[t], s, 0, 0, 0);       // rows = queries, col = key
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[t], vf[t], dp, 0, 0, 0);
-        }
         const bool tail = qt + 32 > kend;
+        float Lr[16], Dr[16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 L4 = *reinterpret_cast<const float4*>(&Ls[8 * g + 4 * h]);
-            const float4 D4 = *reinterpret_cast<const float4*>(&Ds[8 * g + 4 * h]);
-            const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+        for (int j = 0; j < 4; ++j) {
+            const float4 L4 = *reinterpret_cast<const float4*>(&Ls[8 * j + 4 * h]);
+            const float4 D4 = *reinterpret_cast<const float4*>(&Ds[8 * j + 4 * h]);
+            Lr[4 * j] = L4.x; Lr[4 * j + 1] = L4.y; Lr[4 * j + 2] = L4.z; Lr[4 * j + 3] = L4.w;
+            Dr[4 * j] = D4.x; Dr[4 * j + 1] = D4.y; Dr[4 * j + 2] = D4.z; Dr[4 * j + 3] = D4.w;
+        }
+        bf16x8 pf[2][2], df[2][2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * g + j;
-                float p = exp2f(s[r] - Lr[j]);
-                if (tail && qt + 8 * g + 4 * h + j >= kend) p = 0.0f;
-                s[r] = p;
-                dp[r] = p * (dp[r] - Dr[j]);
+        for (int g = 0; g < 2; ++g) {
+            f32x16 s, dp;
+            zero_acc(s); zero_acc(dp);
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[t], kf[g][t], s, 0, 0, 0);       // rows = queries, col = key
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[t], vf[g][t], dp, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = exp2f(fmaf(s[r], scale2, -Lr[r]));
+                if (tail && qt + acc_row(r, h) >= kend) p = 0.0f;
+                s[r] = p;
+                dp[r] = p * (dp[r] - Dr[r]);
+            }
+            pf[g][0] = attn_pack8(s, 0); pf[g][1] = attn_pack8(s, 1);
+            df[g][0] = attn_pack8(dp, 0); df[g][1] = attn_pack8(dp, 1);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bf16x8 pf = attn_pack8(s, t), df = attn_pack8(dp, t);
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_tr_frag(Gs, VP, t, nb * 32, lane), pf, dv[nb], 0, 0, 0);
-                dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_tr_frag(Qs, VP, t, nb * 32, lane), df, dk[nb], 0, 0, 0);
+                const bf16x8 gt = attn_tr_frag(Gs, VP, t, nb * 32, lane), qtf = attn_tr_frag(Qs, VP, t, nb * 32, lane);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    dv[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf[g][t], dv[g][nb], 0, 0, 0);
+                    dk[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, df[g][t], dk[g][nb], 0, 0, 0);
+                }
             }
-        }
     }
-    if (kj < kend) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+    for (int g = 0; g < 2; ++g) {
+        const int kj = k0 + 32 * g + c;
+        if (kj < kend) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const long long o = (long long)kj * lddq + head * DH + nb * 32 + 8 * g + 4 * h;
-                *reinterpret_cast<float4*>(dqkv + o + E) =
-                    make_float4(dk[nb][4 * g] * scale, dk[nb][4 * g + 1] * scale, dk[nb][4 * g + 2] * scale, dk[nb][4 * g + 3] * scale);
-                *reinterpret_cast<float4*>(dqkv + o + 2 * E) =
-                    make_float4(dv[nb][4 * g], dv[nb][4 * g + 1], dv[nb][4 * g + 2], dv[nb][4 * g + 3]);
-            }
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long long o = (long long)kj * lddq + head * DH + nb * 32 + 8 * j + 4 * h;
+                    attn_store4(dqkv + o + E, dk[g][nb][4 * j] * scale, dk[g][nb][4 * j + 1] * scale, dk[g][nb][4 * j + 2] * scale,
+                                dk[g][nb][4 * j + 3] * scale);
+                    attn_store4(dqkv + o + 2 * E, dv[g][nb][4 * j], dv[g][nb][4 * j + 1], dv[g][nb][4 * j + 2], dv[g][nb][4 * j + 3]);
+                }
+        }
     }
 }
 
@@ -562,50 +639,50 @@ static bool attn_shape_ok(int DH, long long ld, long long ldo) {
     return (DH == 8 || DH == 16 || DH == 32 || DH == 64) && ld % 4 == 0 && ldo % 4 == 0;
 }
 
-hipError_t launch_attn_fwd(int mode, const float* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
-                           int B, int N, float* out, long long ldo, float* lse2, hipStream_t st) {
+hipError_t launch_attn_fwd(int lowp, const void* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
+                           int B, int N, void* out, long long ldo, float* lse2, hipStream_t st) {
     if (N == 0 || B == 0) return hipSuccess;
-    if (!attn_shape_ok(DH, ld, ldo)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(N / ATT_TILE + B), (unsigned)H), block(ATT_TILE);
     const float scale2 = LOG2E / sqrtf((float)DH);
-    if (mode == 1 && (DH == 32 || DH == 64)) {            // bf16 operands on the matrix core
-        const dim3 grid2(2 * grid.x, (unsigned)H);
-        if (DH == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<1>), grid2, block, 0, st, qkv, ld, H, ptr, tile_ptr, B, scale2, out, ldo, lse2);
-        else hipLaunchKernelGGL((attn_fwd_mfma_kernel<2>), grid2, block, 0, st, qkv, ld, H, ptr, tile_ptr, B, scale2, out, ldo, lse2);
+    if (lowp) {                                           // bf16 tensors, matrix core
+        if ((DH != 32 && DH != 64) || ld % 8 || ldo % 8) return hipErrorInvalidValue;
+        if (DH == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<1>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, B, scale2, (__bf16*)out, ldo, lse2);
+        else hipLaunchKernelGGL((attn_fwd_mfma_kernel<2>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, B, scale2, (__bf16*)out, ldo, lse2);
         return hipGetLastError();
     }
-#define GN_ATT(D) hipLaunchKernelGGL((attn_fwd_kernel<D>), grid, block, 0, st, qkv, ld, H, ptr, tile_ptr, B, scale2, out, ldo, lse2)
+    if (!attn_shape_ok(DH, ld, ldo)) return hipErrorInvalidValue;
+#define GN_ATT(D) hipLaunchKernelGGL((attn_fwd_kernel<D>), grid, block, 0, st, (const float*)qkv, ld, H, ptr, tile_ptr, B, scale2, (float*)out, ldo, lse2)
     switch (DH) { case 8: GN_ATT(8); break; case 16: GN_ATT(16); break; case 32: GN_ATT(32); break; default: GN_ATT(64); }
 #undef GN_ATT
     return hipGetLastError();
 }
 
-hipError_t launch_attn_bwd(int mode, const float* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
-                           int B, int N, const float* out, long long ldo, const float* dout, long long lddo,
-                           const float* lse2, float* delta, float* dqkv, long long lddq, hipStream_t st) {
+hipError_t launch_attn_bwd(int lowp, const void* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
+                           int B, int N, const void* out, long long ldo, const void* dout, long long lddo,
+                           const float* lse2, float* delta, void* dqkv, long long lddq, hipStream_t st) {
     if (N == 0 || B == 0) return hipSuccess;
-    if (!attn_shape_ok(DH, ld, ldo) || lddo % 4 || lddq % 4) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(N / ATT_TILE + B), (unsigned)H), block(ATT_TILE);
     const float scale = 1.0f / sqrtf((float)DH);
-    if (mode == 1 && (DH == 32 || DH == 64)) {
-        const dim3 grid2(2 * grid.x, (unsigned)H);
+    if (lowp) {
+        if ((DH != 32 && DH != 64) || ld % 8 || ldo % 8 || lddo % 8 || lddq % 8) return hipErrorInvalidValue;
 #define GN_ATTM(NB_)                                                                                                \
     {                                                                                                               \
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NB_>), grid2, block, 0, st, qkv, ld, H, ptr, tile_ptr, B, scale, out, \
-                           ldo, dout, lddo, lse2, delta, dqkv, lddq);                                               \
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<NB_>), grid2, block, 0, st, qkv, ld, H, ptr, tile_ptr, B, scale, dout, \
-                           lddo, lse2, delta, dqkv, lddq);                                                          \
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NB_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, B, \
+                           scale, (const __bf16*)out, ldo, (const __bf16*)dout, lddo, lse2, delta, (__bf16*)dqkv, lddq); \
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<NB_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, B, \
+                           scale, (const __bf16*)dout, lddo, lse2, delta, (__bf16*)dqkv, lddq);                     \
     }
         if (DH == 32) GN_ATTM(1) else GN_ATTM(2)
 #undef GN_ATTM
         return hipGetLastError();
     }
+    if (!attn_shape_ok(DH, ld, ldo) || lddo % 4 || lddq % 4) return hipErrorInvalidValue;
 #define GN_ATT(D)                                                                                                  \
     {                                                                                                              \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), grid, block, 0, st, qkv, ld, H, ptr, tile_ptr, B, scale, out, ldo, \
-                           dout, lddo, lse2, delta, dqkv, lddq);                                                   \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), grid, block, 0, st, qkv, ld, H, ptr, tile_ptr, B, scale, dout, \
-                           lddo, lse2, delta, dqkv, lddq);                                                         \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), grid, block, 0, st, (const float*)qkv, ld, H, ptr, tile_ptr, B, scale, \
+                           (const float*)out, ldo, (const float*)dout, lddo, lse2, delta, (float*)dqkv, lddq);     \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), grid, block, 0, st, (const float*)qkv, ld, H, ptr, tile_ptr, B, scale, \
+                           (const float*)dout, lddo, lse2, delta, (float*)dqkv, lddq);                             \
     }
     switch (DH) { case 8: GN_ATT(8) break; case 16: GN_ATT(16) break; case 32: GN_ATT(32) break; default: GN_ATT(64) }
 #undef GN_ATT

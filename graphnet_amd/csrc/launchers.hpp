@@ -72,10 +72,10 @@ hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr,
 hipError_t launch_pool_bwd(const float* gout, int C, const int* ptr, const int* batch, int N, const int* codes, int ns,
                            const int* argmin, const int* argmax, const float* gate, long long ldgate, void* dx,
                            long long lddx, int dx_lowp, hipStream_t st);
-// attn.hip
-hipError_t launch_attn_fwd(int mode, const float* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr, int B,
-                           int N, float* out, long long ldo, float* lse2, hipStream_t st);
-hipError_t launch_attn_bwd(int mode, const float* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr, int B,
-                           int N, const float* out, long long ldo, const float* dout, long long lddo,
-                           const float* lse2, float* delta, float* dqkv, long long lddq, hipStream_t st);
+// attn.hip  (lowp: qkv / out / dout / dqkv are bf16 and the MFMA kernels run; else fp32 on the vector ALU)
+hipError_t launch_attn_fwd(int lowp, const void* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
+                           int B, int N, void* out, long long ldo, float* lse2, hipStream_t st);
+hipError_t launch_attn_bwd(int lowp, const void* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
+                           int B, int N, const void* out, long long ldo, const void* dout, long long lddo,
+                           const float* lse2, float* delta, void* dqkv, long long lddq, hipStream_t st);
 }  // namespace gn

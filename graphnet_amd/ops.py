@@ -584,34 +584,40 @@ def segment_pool_bwd(gout: Tensor, C: int, ptr: Tensor, batch: Tensor, N: int, s
 
 
 # ------------------------------------------------------------------------------ ragged self attention (DynTrans)
-def attention_fwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, mode: int = MODE_F32):
+def attention_lowp(mode: int, d_model: int, n_head: int) -> bool:
+    """bf16 tensors + matrix-core kernels are available for head widths 32 and 64 in bf16 mode."""
+    return mode == MODE_BF16 and d_model % n_head == 0 and d_model // n_head in (32, 64)
+
+
+def attention_fwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor):
     """``softmax(Q K^T / sqrt(dh)) V`` per head, every pulse attending to its own event (``gn_attention_fwd``).
-    ``qkv`` fp32 ``[N, 3 d]`` (Q | K | V); ``plan`` from :func:`knn_plan`.  -> (out [N, d], lse2 [N, H])."""
-    _need(qkv, torch.float32, "qkv")
+    ``qkv`` ``[N, 3 d]`` (Q | K | V): fp32 -> exact-fp32 kernels, bf16 -> matrix-core kernels (dh 32 / 64);
+    ``plan`` from :func:`knn_plan`.  -> (out [N, d] in qkv's type, lse2 [N, H] fp32)."""
+    if qkv.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("qkv must be fp32 or bf16")
     N, d3 = int(qkv.shape[0]), int(qkv.shape[1])
     d = d3 // 3
     if d3 != 3 * d or d % n_head:
         raise ValueError("qkv must be [N, 3*d] with d a multiple of the number of heads")
     B = int(ptr.shape[0]) - 1
-    out = torch.empty((N, d), dtype=torch.float32, device=qkv.device)
+    out = torch.empty((N, d), dtype=qkv.dtype, device=qkv.device)
     lse2 = torch.empty((N, n_head), dtype=torch.float32, device=qkv.device)
     with _timed("attention_fwd"):
-        _lib.check(_lib.lib().gn_attention_fwd(mode, _p(qkv), _rows(qkv, "qkv"), n_head, d // n_head, _p(ptr), _p(plan), B, N,
-                                               _p(out), d, _p(lse2), _st()))
+        _lib.check(_lib.lib().gn_attention_fwd(int(qkv.dtype == torch.bfloat16), _p(qkv), _rows(qkv, "qkv"), n_head,
+                                               d // n_head, _p(ptr), _p(plan), B, N, _p(out), d, _p(lse2), _st()))
     return out, lse2
 
 
-def attention_bwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, out: Tensor, lse2: Tensor, dout: Tensor,
-                  mode: int = MODE_F32) -> Tensor:
-    """Gradient of :func:`attention_fwd` w.r.t. ``qkv`` -> [N, 3 d] fp32."""
-    _need(qkv, torch.float32, "qkv"); _need(dout, torch.float32, "dout"); _need(out, torch.float32, "out")
+def attention_bwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, out: Tensor, lse2: Tensor, dout: Tensor) -> Tensor:
+    """Gradient of :func:`attention_fwd` w.r.t. ``qkv`` -> [N, 3 d] in qkv's type (``out`` / ``dout`` likewise)."""
+    _need(dout, qkv.dtype, "dout"); _need(out, qkv.dtype, "out")
     N, d3 = int(qkv.shape[0]), int(qkv.shape[1])
     d = d3 // 3
     B = int(ptr.shape[0]) - 1
-    dqkv = torch.empty((N, d3), dtype=torch.float32, device=qkv.device)
+    dqkv = torch.empty((N, d3), dtype=qkv.dtype, device=qkv.device)
     delta = torch.empty((N, n_head), dtype=torch.float32, device=qkv.device)
     with _timed("attention_bwd"):
-        _lib.check(_lib.lib().gn_attention_bwd(mode, _p(qkv), _rows(qkv, "qkv"), n_head, d // n_head, _p(ptr), _p(plan), B, N,
-                                               _p(out), _rows(out, "out"), _p(dout), _rows(dout, "dout"), _p(lse2),
-                                               _p(delta), _p(dqkv), d3, _st()))
+        _lib.check(_lib.lib().gn_attention_bwd(int(qkv.dtype == torch.bfloat16), _p(qkv), _rows(qkv, "qkv"), n_head,
+                                               d // n_head, _p(ptr), _p(plan), B, N, _p(out), _rows(out, "out"), _p(dout),
+                                               _rows(dout, "dout"), _p(lse2), _p(delta), _p(dqkv), d3, _st()))
     return dqkv

@@ -66,8 +66,9 @@ class _DynTransFunction(torch.autograd.Function):
         r = conv.add_(x) if residual else conv
         y0, st0 = ops.rownorm_act_fwd(r, d, "identity", g0, be0)        # self.norm1
         # --- TransformerEncoderLayer, norm_first=False
-        qkv = ops.linear_fwd(mode, _ksegs([(y0, d)]), _wt(mode, Win, [d]), 3 * d, bias=bin_.contiguous())
-        att, lse2 = ops.attention_fwd(qkv, H, ptr, plan, mode)
+        lowp = ops.attention_lowp(mode, d, H)       # bf16 qkv / attention output, matrix-core attention kernels
+        qkv = ops.linear_fwd(mode, _ksegs([(y0, d)]), _wt(mode, Win, [d]), 3 * d, bias=bin_.contiguous(), out_lowp=lowp)
+        att, lse2 = ops.attention_fwd(qkv, H, ptr, plan)
         z1 = y0.clone()
         ops.linear_fwd(mode, _ksegs([(att, d)]), _wt(mode, Wout, [d]), d, bias=bout.contiguous(), out=z1, accum=True)
         y1, st1 = ops.rownorm_act_fwd(z1, d, "identity", g1, be1)
@@ -102,8 +103,8 @@ class _DynTransFunction(torch.autograd.Function):
         # norm1, attention
         dz1, grads[14], grads[15] = ops.rownorm_act_bwd(dz3, z1, d, "identity", g1, be1, st1)
         grads[8], grads[9] = ops.linear_wgrad(mode, dz1, d, _ksegs([(att, d)]), with_bias=True)
-        datt = ops.linear_fwd(mode, _ksegs([(dz1, d)]), _wt(mode, Wout.t(), [d]), d)
-        dqkv = ops.attention_bwd(qkv, H, ptr, plan, att, lse2, datt, mode)
+        datt = ops.linear_fwd(mode, _ksegs([(dz1, d)]), _wt(mode, Wout.t(), [d]), d, out_lowp=qkv.dtype == torch.bfloat16)
+        dqkv = ops.attention_bwd(qkv, H, ptr, plan, att, lse2, datt)
         grads[6], grads[7] = ops.linear_wgrad(mode, dqkv, 3 * d, _ksegs([(y0, d)]), with_bias=True)
         ops.linear_fwd(mode, _ksegs([(dqkv, 3 * d)]), _wt(mode, Win.t(), [3 * d]), d, out=dz1, accum=True)  # dy0
         # DynTrans.norm1

@@ -211,17 +211,18 @@ int gn_segment_pool_bwd(const float* gout, int32_t C, const int32_t* ptr, const 
 
 /* ---- ragged multi-head self attention (DynTrans, models/components/layers.py:166-197) ---- */
 /* Replaces to_dense_batch + torch.nn.TransformerEncoder's attention + x[mask]: every pulse attends to the
- * pulses of its own event (ptr), nothing is padded.  qkv[N, ld] fp32 = [Q | K | V], each H*DH wide (the in_proj
+ * pulses of its own event (ptr), nothing is padded.  qkv[N, ld] = [Q | K | V], each H*DH wide (the in_proj
  * output); tile_ptr from gn_knn_plan; out[N, ldo] = softmax(Q K^T / sqrt(DH)) V per head, heads side by side;
- * lse2[N, H] = log2 of the softmax denominators (saved for the backward).  gn_attention_bwd: dqkv[N, lddq] =
- * gradient w.r.t. qkv given dout; delta[N, H] is scratch.  DH in {8, 16, 32, 64}.  mode 0: exact fp32 on the
- * vector ALU; mode 1: bf16 operands on the matrix core for DH in {32, 64} (fp32 softmax statistics and
- * accumulation), the fp32 kernels otherwise. */
-int gn_attention_fwd(int32_t mode, const float* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr, const int32_t* tile_ptr,
-                     int32_t B, int32_t N, float* out, int64_t ldo, float* lse2, void* stream);
-int gn_attention_bwd(int32_t mode, const float* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr, const int32_t* tile_ptr,
-                     int32_t B, int32_t N, const float* out, int64_t ldo, const float* dout, int64_t lddo,
-                     const float* lse2, float* delta, float* dqkv, int64_t lddq, void* stream);
+ * lse2[N, H] fp32 = log2 of the softmax denominators (saved for the backward).  gn_attention_bwd: dqkv[N, lddq] =
+ * gradient w.r.t. qkv given dout; delta[N, H] fp32 is scratch.
+ * lowp = 0: qkv / out / dout / dqkv are fp32, exact-fp32 kernels on the vector ALU, DH in {8, 16, 32, 64}.
+ * lowp = 1: those four tensors are bf16, products on the matrix core (fp32 softmax statistics and accumulation),
+ *           DH in {32, 64}. */
+int gn_attention_fwd(int32_t lowp, const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr,
+                     const int32_t* tile_ptr, int32_t B, int32_t N, void* out, int64_t ldo, float* lse2, void* stream);
+int gn_attention_bwd(int32_t lowp, const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr,
+                     const int32_t* tile_ptr, int32_t B, int32_t N, const void* out, int64_t ldo, const void* dout,
+                     int64_t lddo, const float* lse2, float* delta, void* dqkv, int64_t lddq, void* stream);
 
 #ifdef __cplusplus
 }
