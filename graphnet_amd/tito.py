@@ -73,7 +73,8 @@ class _DynTransFunction(torch.autograd.Function):
         ops.linear_fwd(mode, _ksegs([(att, d)]), _wt(mode, Wout, [d]), d, bias=bout.contiguous(), out=z1, accum=True)
         y1, st1 = ops.rownorm_act_fwd(z1, d, "identity", g1, be1)
         F = int(Wl1.shape[0])
-        h = ops.linear_fwd(mode, _ksegs([(y1, d)]), _wt(mode, Wl1, [d]), F, bias=bl1.contiguous(), relu=True)
+        h = ops.linear_fwd(mode, _ksegs([(y1, d)]), _wt(mode, Wl1, [d]), F, bias=bl1.contiguous(), relu=True,
+                           out_lowp=mode == ops.MODE_BF16)     # the 2048-wide hidden layer is stored in the operand type
         z3 = y1.clone()
         ops.linear_fwd(mode, _ksegs([(h, F)]), _wt(mode, Wl2, [F]), d, bias=bl2.contiguous(), out=z3, accum=True)
         y2, st2 = ops.rownorm_act_fwd(z3, d, "identity", g2, be2)
@@ -97,7 +98,7 @@ class _DynTransFunction(torch.autograd.Function):
         # norm2, FFN
         dz3, grads[16], grads[17] = ops.rownorm_act_bwd(gy, z3, d, "identity", g2, be2, st2)
         grads[12], grads[13] = ops.linear_wgrad(mode, dz3, d, _ksegs([(h, F)]), with_bias=True)
-        dh = ops.linear_fwd(mode, _ksegs([(dz3, d)]), _wt(mode, Wl2.t(), [d]), F, gate=h)
+        dh = ops.linear_fwd(mode, _ksegs([(dz3, d)]), _wt(mode, Wl2.t(), [d]), F, gate=h, out_lowp=h.dtype == torch.bfloat16)
         grads[10], grads[11] = ops.linear_wgrad(mode, dh, F, _ksegs([(y1, d)]), with_bias=True)
         ops.linear_fwd(mode, _ksegs([(dh, F)]), _wt(mode, Wl1.t(), [F]), d, out=dz3, accum=True)      # dy1
         # norm1, attention

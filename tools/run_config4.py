@@ -9,7 +9,7 @@ from graphnet_amd import ops
 from graphnet_amd.synthetic import synthetic_icecube86_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+steps = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 5
 torch.manual_seed(0)
 b = synthetic_icecube86_batch(B, seed=5, count_range=(50, 3000)).to("cuda")
 m = g.StandardModel(
@@ -38,3 +38,15 @@ n = b.n_pulses.double()
 print(f"config4 B={B} N={b.x.shape[0]} (pulses/event {int(n.min())}..{int(n.max())}, sum n^2 = {float((n*n).sum()):.3g}) {dtype}: "
       f"{1e3*dt:.1f} ms/step  {B/dt:.1f} events/s  {b.x.shape[0]/dt/1e6:.2f} Mpulses/s  loss {float(l):.4f}")
 print({k: round(ms / steps, 3) for k, (n_, ms) in ops.timer_summary().items()})
+if "--cpu-baseline" in sys.argv:     # the oracle (CPU restatement, test infrastructure) timed on a bounded sample
+    from oracle import dynedge_oracle, tito_oracle
+    nb = 8
+    bc = synthetic_icecube86_batch(nb, seed=5, count_range=(50, 3000))
+    ref = tito_oracle.DynEdgeTITOOracle(7, global_pooling_schemes=["max"])
+    ei = dynedge_oracle.knn_graph(bc.x, 8, bc.batch, [0, 1, 2])
+    t0 = time.perf_counter()
+    y = ref(bc.x, ei, bc.batch, bc.n_pulses)
+    y.sum().backward()
+    dtc = time.perf_counter() - t0
+    print(f"cpu oracle (torch CPU, {torch.get_num_threads()} threads): {nb} events / {bc.x.shape[0]} pulses fwd+bwd in {dtc:.2f} s "
+          f"= {nb/dtc:.2f} events/s, {bc.x.shape[0]/dtc/1e3:.1f} kpulses/s")
