@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphnet_amd.so")
@@ -17,6 +17,7 @@ _lib = None
 P = c_void_p
 I32 = c_int32
 I64 = c_int64
+U32 = c_uint32
 
 # name -> (restype, argtypes); mirrors include/graphnet_amd.h one to one
 SIGNATURES = {
@@ -58,8 +59,9 @@ SIGNATURES = {
     "gn_pack_weights": (I32, [P, I32, P]),
     "gn_segment_pool_fwd": (I32, [P, I64, I32, P, I32, P, I32, P, P, P, P]),
     "gn_segment_pool_bwd": (I32, [P, I32, P, P, I32, P, I32, P, P, P, I64, P, I64, I32, P]),
-    "gn_attention_fwd": (I32, [I32, P, I64, I32, I32, P, P, I32, I32, P, I64, P, P]),
-    "gn_attention_bwd": (I32, [I32, P, I64, I32, I32, P, P, I32, I32, P, I64, P, I64, P, P, P, I64, P]),
+    "gn_attention_fwd": (I32, [I32, P, I64, I32, I32, P, P, I32, I32, P, I64, P, U32, U32, P]),
+    "gn_attention_bwd": (I32, [I32, P, I64, I32, I32, P, P, I32, I32, P, I64, P, I64, P, P, P, I64, U32, U32, P]),
+    "gn_dropout": (I32, [P, I64, I32, P, I64, P, I64, I32, I64, I32, U32, U32, P]),
 }
 
 

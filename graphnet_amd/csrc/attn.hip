@@ -39,10 +39,10 @@ __device__ __forceinline__ void attn_stage(float* __restrict__ dst, const float*
     }
 }
 
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(64) void attn_fwd_kernel(
     const float* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
-    int B, float scale2, float* __restrict__ out, long long ldo, float* __restrict__ lse2) {
+    int B, float scale2, float* __restrict__ out, long long ldo, float* __restrict__ lse2, Drop dr) {
     __shared__ float Ks[ATT_TILE * DH];
     __shared__ float Vs[ATT_TILE * DH];
     const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
@@ -93,8 +93,9 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(
             for (int d = 0; d < DH; ++d) o[d] *= corr;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const float p = exp2f(s[t] - mn);
+                float p = exp2f(s[t] - mn);
                 l += p;
+                if constexpr (DROP) p = gn_keep(dr.seed, (unsigned)qi, (unsigned)((kt + c + t) * H + head), dr.thresh) ? p * dr.inv : 0.0f;
                 const float* vr = Vs + (c + t) * DH;
 #pragma unroll
                 for (int d4 = 0; d4 < DH / 4; ++d4) {
@@ -117,11 +118,11 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(
 }
 
 // dQ pass: lane = query.  Also writes delta[i, h] = sum_d dO[i,d] O[i,d] for the dK/dV pass.
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(
     const float* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
     int B, float scale, const float* __restrict__ out, long long ldo, const float* __restrict__ dout, long long lddo,
-    const float* __restrict__ lse2, float* __restrict__ delta, float* __restrict__ dqkv, long long lddq) {
+    const float* __restrict__ lse2, float* __restrict__ delta, float* __restrict__ dqkv, long long lddq, Drop dr) {
     __shared__ float Ks[ATT_TILE * DH];
     __shared__ float Vs[ATT_TILE * DH];
     const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(
                         dp = fmaf(go[4 * d4], vv.x, dp); dp = fmaf(go[4 * d4 + 1], vv.y, dp);
                         dp = fmaf(go[4 * d4 + 2], vv.z, dp); dp = fmaf(go[4 * d4 + 3], vv.w, dp);
                     }
+                    if constexpr (DROP) dp = gn_keep(dr.seed, (unsigned)qi, (unsigned)((kt + c + t) * H + head), dr.thresh) ? dp * dr.inv : 0.0f;
                     const float ds = exp2f(s - ls) * (dp - dl);
 #pragma unroll
                     for (int d4 = 0; d4 < DH / 4; ++d4) {
@@ -191,11 +193,11 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(
 }
 
 // dK / dV pass: lane = key; queries of the event stream through LDS.
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(
     const float* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
     int B, float scale, const float* __restrict__ dout, long long lddo, const float* __restrict__ lse2,
-    const float* __restrict__ delta, float* __restrict__ dqkv, long long lddq) {
+    const float* __restrict__ delta, float* __restrict__ dqkv, long long lddq, Drop dr) {
     __shared__ float Qs[ATT_TILE * DH];
     __shared__ float Gs[ATT_TILE * DH];
     __shared__ float Ls[ATT_TILE];
@@ -247,8 +249,14 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(
                         dp = fmaf(v[4 * d4], gg.x, dp); dp = fmaf(v[4 * d4 + 1], gg.y, dp);
                         dp = fmaf(v[4 * d4 + 2], gg.z, dp); dp = fmaf(v[4 * d4 + 3], gg.w, dp);
                     }
-                    const float p = exp2f(s - Ls[c + t]);
-                    const float ds = p * (dp - Ds[c + t]);
+                    const float p0 = exp2f(s - Ls[c + t]);
+                    float p = p0;
+                    if constexpr (DROP) {
+                        const bool keep = gn_keep(dr.seed, (unsigned)(qt + c + t), (unsigned)(kj * H + head), dr.thresh);
+                        p = keep ? p0 * dr.inv : 0.0f;
+                        dp = keep ? dp * dr.inv : 0.0f;
+                    }
+                    const float ds = p0 * (dp - Ds[c + t]);
 #pragma unroll
                     for (int d4 = 0; d4 < DH / 4; ++d4) {
                         const float4 qq = *reinterpret_cast<const float4*>(qr + 4 * d4);
@@ -312,10 +320,10 @@ __device__ __forceinline__ bf16x8 attn_tr_frag(const unsigned char* tile, int pi
     return __builtin_bit_cast(bf16x8, av);
 }
 
-template <int NB>
+template <int NB, bool DROP>
 __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(
     const __bf16* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
-    int B, float scale2, __bf16* __restrict__ out, long long ldo, float* __restrict__ lse2) {
+    int B, float scale2, __bf16* __restrict__ out, long long ldo, float* __restrict__ lse2, Drop dr) {
     constexpr int DH = 32 * NB, KS = DH / 16, VP = attn_tr_pitch(DH * 2);
     __shared__ __attribute__((aligned(16))) unsigned char Vs[32 * VP];
     const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
@@ -377,7 +385,12 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(
             const float corr = exp2f(m[g] - mn);
             float ps = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = exp2f(fmaf(s[r], scale2, -mn)); ps += s[r]; }
+            for (int r = 0; r < 16; ++r) {
+                s[r] = exp2f(fmaf(s[r], scale2, -mn));
+                ps += s[r];
+                if constexpr (DROP)
+                    s[r] = gn_keep(dr.seed, (unsigned)(q0 + 32 * g + c), (unsigned)((kt + acc_row(r, h)) * H + head), dr.thresh) ? s[r] * dr.inv : 0.0f;
+            }
             l[g] = l[g] * corr + ps;
             m[g] = mn;
 #pragma unroll
@@ -413,11 +426,11 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(
     }
 }
 
-template <int NB>
+template <int NB, bool DROP>
 __global__ __launch_bounds__(64) void attn_bwd_dq_mfma_kernel(
     const __bf16* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
     int B, float scale, const __bf16* __restrict__ out, long long ldo, const __bf16* __restrict__ dout, long long lddo,
-    const float* __restrict__ lse2, float* __restrict__ delta, __bf16* __restrict__ dqkv, long long lddq) {
+    const float* __restrict__ lse2, float* __restrict__ delta, __bf16* __restrict__ dqkv, long long lddq, Drop dr) {
     constexpr int DH = 32 * NB, KS = DH / 16, VP = attn_tr_pitch(DH * 2);
     __shared__ __attribute__((aligned(16))) unsigned char Ks[32 * VP];
     const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
@@ -483,7 +496,10 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_mfma_kernel(
             for (int r = 0; r < 16; ++r) {
                 float p = exp2f(fmaf(s[r], scale2, -ls[g]));
                 if (tail && kt + acc_row(r, h) >= kend) p = 0.0f;
-                s[r] = p * (dp[r] - dl[g]);
+                float dpr = dp[r];
+                if constexpr (DROP)
+                    dpr = gn_keep(dr.seed, (unsigned)(q0 + 32 * g + c), (unsigned)((kt + acc_row(r, h)) * H + head), dr.thresh) ? dpr * dr.inv : 0.0f;
+                s[r] = p * (dpr - dl[g]);
             }
             df[g][0] = attn_pack8(s, 0);
             df[g][1] = attn_pack8(s, 1);
@@ -512,11 +528,11 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_mfma_kernel(
     }
 }
 
-template <int NB>
+template <int NB, bool DROP>
 __global__ __launch_bounds__(64) void attn_bwd_dkv_mfma_kernel(
     const __bf16* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
     int B, float scale, const __bf16* __restrict__ dout, long long lddo, const float* __restrict__ lse2,
-    const float* __restrict__ delta, __bf16* __restrict__ dqkv, long long lddq) {
+    const float* __restrict__ delta, __bf16* __restrict__ dqkv, long long lddq, Drop dr) {
     constexpr int DH = 32 * NB, KS = DH / 16, VP = attn_tr_pitch(DH * 2);
     __shared__ __attribute__((aligned(16))) unsigned char Qs[32 * VP];
     __shared__ __attribute__((aligned(16))) unsigned char Gs[32 * VP];
@@ -600,8 +616,14 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_mfma_kernel(
             for (int r = 0; r < 16; ++r) {
                 float p = exp2f(fmaf(s[r], scale2, -Lr[r]));
                 if (tail && qt + acc_row(r, h) >= kend) p = 0.0f;
-                s[r] = p;
-                dp[r] = p * (dp[r] - Dr[r]);
+                float pd = p, dpr = dp[r];
+                if constexpr (DROP) {
+                    const bool keep = gn_keep(dr.seed, (unsigned)(qt + acc_row(r, h)), (unsigned)((k0 + 32 * g + c) * H + head), dr.thresh);
+                    pd = keep ? p * dr.inv : 0.0f;
+                    dpr = keep ? dpr * dr.inv : 0.0f;
+                }
+                s[r] = pd;
+                dp[r] = p * (dpr - Dr[r]);
             }
             pf[g][0] = attn_pack8(s, 0); pf[g][1] = attn_pack8(s, 1);
             df[g][0] = attn_pack8(dp, 0); df[g][1] = attn_pack8(dp, 1);
@@ -639,52 +661,73 @@ static bool attn_shape_ok(int DH, long long ld, long long ldo) {
     return (DH == 8 || DH == 16 || DH == 32 || DH == 64) && ld % 4 == 0 && ldo % 4 == 0;
 }
 
+static Drop make_drop(unsigned seed, unsigned thresh) {
+    Drop dr;
+    dr.seed = seed; dr.thresh = thresh; dr.inv = (float)(1.0 / (1.0 - (double)thresh / 4294967296.0));
+    return dr;
+}
+
 hipError_t launch_attn_fwd(int lowp, const void* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
-                           int B, int N, void* out, long long ldo, float* lse2, hipStream_t st) {
+                           int B, int N, void* out, long long ldo, float* lse2, unsigned seed, unsigned thresh,
+                           hipStream_t st) {
     if (N == 0 || B == 0) return hipSuccess;
     const dim3 grid((unsigned)(N / ATT_TILE + B), (unsigned)H), block(ATT_TILE);
     const float scale2 = LOG2E / sqrtf((float)DH);
+    const Drop dr = make_drop(seed, thresh);
+    const bool drop = thresh != 0;
+    if ((long long)N * H >= (1ll << 32)) return hipErrorInvalidValue;      // dropout counters are 32-bit
     if (lowp) {                                           // bf16 tensors, matrix core
         if ((DH != 32 && DH != 64) || ld % 8 || ldo % 8) return hipErrorInvalidValue;
-        if (DH == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<1>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, B, scale2, (__bf16*)out, ldo, lse2);
-        else hipLaunchKernelGGL((attn_fwd_mfma_kernel<2>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, B, scale2, (__bf16*)out, ldo, lse2);
+#define GN_ATTM(NB_, DR_) hipLaunchKernelGGL((attn_fwd_mfma_kernel<NB_, DR_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, B, scale2, (__bf16*)out, ldo, lse2, dr)
+        if (DH == 32) { if (drop) GN_ATTM(1, true); else GN_ATTM(1, false); }
+        else { if (drop) GN_ATTM(2, true); else GN_ATTM(2, false); }
+#undef GN_ATTM
         return hipGetLastError();
     }
     if (!attn_shape_ok(DH, ld, ldo)) return hipErrorInvalidValue;
-#define GN_ATT(D) hipLaunchKernelGGL((attn_fwd_kernel<D>), grid, block, 0, st, (const float*)qkv, ld, H, ptr, tile_ptr, B, scale2, (float*)out, ldo, lse2)
-    switch (DH) { case 8: GN_ATT(8); break; case 16: GN_ATT(16); break; case 32: GN_ATT(32); break; default: GN_ATT(64); }
+#define GN_ATT(D, DR_) hipLaunchKernelGGL((attn_fwd_kernel<D, DR_>), grid, block, 0, st, (const float*)qkv, ld, H, ptr, tile_ptr, B, scale2, (float*)out, ldo, lse2, dr)
+#define GN_ATT2(D) { if (drop) GN_ATT(D, true); else GN_ATT(D, false); }
+    switch (DH) { case 8: GN_ATT2(8) break; case 16: GN_ATT2(16) break; case 32: GN_ATT2(32) break; default: GN_ATT2(64) }
+#undef GN_ATT2
 #undef GN_ATT
     return hipGetLastError();
 }
 
 hipError_t launch_attn_bwd(int lowp, const void* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
                            int B, int N, const void* out, long long ldo, const void* dout, long long lddo,
-                           const float* lse2, float* delta, void* dqkv, long long lddq, hipStream_t st) {
+                           const float* lse2, float* delta, void* dqkv, long long lddq, unsigned seed, unsigned thresh,
+                           hipStream_t st) {
     if (N == 0 || B == 0) return hipSuccess;
     const dim3 grid((unsigned)(N / ATT_TILE + B), (unsigned)H), block(ATT_TILE);
     const float scale = 1.0f / sqrtf((float)DH);
+    const Drop dr = make_drop(seed, thresh);
+    const bool drop = thresh != 0;
+    if ((long long)N * H >= (1ll << 32)) return hipErrorInvalidValue;
     if (lowp) {
         if ((DH != 32 && DH != 64) || ld % 8 || ldo % 8 || lddo % 8 || lddq % 8) return hipErrorInvalidValue;
-#define GN_ATTM(NB_)                                                                                                \
+#define GN_ATTM(NB_, DR_)                                                                                           \
     {                                                                                                               \
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NB_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, B, \
-                           scale, (const __bf16*)out, ldo, (const __bf16*)dout, lddo, lse2, delta, (__bf16*)dqkv, lddq); \
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<NB_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, B, \
-                           scale, (const __bf16*)dout, lddo, lse2, delta, (__bf16*)dqkv, lddq);                     \
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NB_, DR_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, \
+                           B, scale, (const __bf16*)out, ldo, (const __bf16*)dout, lddo, lse2, delta, (__bf16*)dqkv, lddq, dr); \
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<NB_, DR_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, \
+                           B, scale, (const __bf16*)dout, lddo, lse2, delta, (__bf16*)dqkv, lddq, dr);              \
     }
-        if (DH == 32) GN_ATTM(1) else GN_ATTM(2)
+        if (DH == 32) { if (drop) GN_ATTM(1, true) else GN_ATTM(1, false) }
+        else { if (drop) GN_ATTM(2, true) else GN_ATTM(2, false) }
 #undef GN_ATTM
         return hipGetLastError();
     }
     if (!attn_shape_ok(DH, ld, ldo) || lddo % 4 || lddq % 4) return hipErrorInvalidValue;
-#define GN_ATT(D)                                                                                                  \
+#define GN_ATT(D, DR_)                                                                                             \
     {                                                                                                              \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), grid, block, 0, st, (const float*)qkv, ld, H, ptr, tile_ptr, B, scale, \
-                           (const float*)out, ldo, (const float*)dout, lddo, lse2, delta, (float*)dqkv, lddq);     \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), grid, block, 0, st, (const float*)qkv, ld, H, ptr, tile_ptr, B, scale, \
-                           (const float*)dout, lddo, lse2, delta, (float*)dqkv, lddq);                             \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<D, DR_>), grid, block, 0, st, (const float*)qkv, ld, H, ptr, tile_ptr, B, \
+                           scale, (const float*)out, ldo, (const float*)dout, lddo, lse2, delta, (float*)dqkv, lddq, dr); \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, DR_>), grid, block, 0, st, (const float*)qkv, ld, H, ptr, tile_ptr, B, \
+                           scale, (const float*)dout, lddo, lse2, delta, (float*)dqkv, lddq, dr);                  \
     }
-    switch (DH) { case 8: GN_ATT(8) break; case 16: GN_ATT(16) break; case 32: GN_ATT(32) break; default: GN_ATT(64) }
+#define GN_ATT2(D) { if (drop) GN_ATT(D, true) else GN_ATT(D, false) }
+    switch (DH) { case 8: GN_ATT2(8) break; case 16: GN_ATT2(16) break; case 32: GN_ATT2(32) break; default: GN_ATT2(64) }
+#undef GN_ATT2
 #undef GN_ATT
     return hipGetLastError();
 }

@@ -262,22 +262,32 @@ int gn_segment_pool_bwd(const float* gout, int32_t C, const int32_t* ptr, const 
 
 
 int gn_attention_fwd(int32_t lowp, const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr,
-                     const int32_t* tile_ptr, int32_t B, int32_t N, void* out, int64_t ldo, float* lse2, void* stream) {
+                     const int32_t* tile_ptr, int32_t B, int32_t N, void* out, int64_t ldo, float* lse2, uint32_t drop_seed,
+                     uint32_t drop_thresh, void* stream) {
     if (H <= 0 || B < 0 || N < 0) return bad("gn_attention_fwd", "H > 0, B >= 0, N >= 0");
-    hipError_t r = gn::launch_attn_fwd(lowp, qkv, ld, H, DH, ptr, tile_ptr, B, N, out, ldo, lse2, S(stream));
+    hipError_t r = gn::launch_attn_fwd(lowp, qkv, ld, H, DH, ptr, tile_ptr, B, N, out, ldo, lse2, drop_seed, drop_thresh,
+                                       S(stream));
     if (r == hipErrorInvalidValue)
         return bad("gn_attention_fwd", "head width in {8,16,32,64} (fp32) or {32,64} (bf16), row pitches multiples of 16 bytes");
     return fail(r, "gn_attention_fwd");
 }
 int gn_attention_bwd(int32_t lowp, const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr,
                      const int32_t* tile_ptr, int32_t B, int32_t N, const void* out, int64_t ldo, const void* dout,
-                     int64_t lddo, const float* lse2, float* delta, void* dqkv, int64_t lddq, void* stream) {
+                     int64_t lddo, const float* lse2, float* delta, void* dqkv, int64_t lddq, uint32_t drop_seed,
+                     uint32_t drop_thresh, void* stream) {
     if (H <= 0 || B < 0 || N < 0) return bad("gn_attention_bwd", "H > 0, B >= 0, N >= 0");
     hipError_t r = gn::launch_attn_bwd(lowp, qkv, ld, H, DH, ptr, tile_ptr, B, N, out, ldo, dout, lddo, lse2, delta, dqkv,
-                                       lddq, S(stream));
+                                       lddq, drop_seed, drop_thresh, S(stream));
     if (r == hipErrorInvalidValue)
         return bad("gn_attention_bwd", "head width in {8,16,32,64} (fp32) or {32,64} (bf16), row pitches multiples of 16 bytes");
     return fail(r, "gn_attention_bwd");
+}
+
+int gn_dropout(const void* x, int64_t ldx, int32_t x_lowp, const float* res, int64_t ldres, void* y, int64_t ldy,
+               int32_t y_lowp, int64_t rows, int32_t cols, uint32_t seed, uint32_t thresh, void* stream) {
+    hipError_t r = gn::launch_dropout(x, ldx, x_lowp, res, ldres, y, ldy, y_lowp, rows, cols, seed, thresh, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_dropout", "cols and row pitches multiples of 4");
+    return fail(r, "gn_dropout");
 }
 
 }  // extern "C"

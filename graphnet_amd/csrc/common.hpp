@@ -168,6 +168,17 @@ __device__ __forceinline__ void coord_store(float* coords, const CoordCols& cc, 
         if (d < cc.n && cc.c[d] == col) { float* p = coords + i * 8 + d; *p = add ? *p + v : v; }
 }
 
+// counter-based dropout decisions (no state, recomputed in the backward): keep element (a, b) of stream `seed`
+// iff hash >= thresh, thresh = round(p * 2^32).  tests/ and oracle/ hold a numpy replica of these two functions.
+__host__ __device__ __forceinline__ unsigned int gn_mix32(unsigned int x) {
+    x ^= x >> 16; x *= 0x21F0AAADu; x ^= x >> 15; x *= 0x735A2D97u; x ^= x >> 15;
+    return x;
+}
+__host__ __device__ __forceinline__ bool gn_keep(unsigned int seed, unsigned int a, unsigned int b, unsigned int thresh) {
+    return gn_mix32(gn_mix32(seed ^ (a * 0x9E3779B1u)) ^ (b * 0x85EBCA77u)) >= thresh;
+}
+struct Drop { unsigned int seed, thresh; float inv; };   // inv = 1 / (1 - thresh / 2^32)
+
 // neighbour table + overflow list of one layer's graph
 struct EdgeGraph {
     const int* nbr;        // [N, K]

@@ -340,6 +340,41 @@ hipError_t launch_slot_reduce_bwd(const float* gout, long long ldg, int C, const
                        aggr, deg, argrow, grows, ldr, Cpad);
     return hipGetLastError();
 }
+// y[r, c] = (res ? res[r, c] : 0) + (keep(r, c) ? x[r, c] * inv : 0)   -- torch.nn.Dropout (+ residual add) and,
+// applied to a gradient with the same seed, its backward.  x / y fp32 or bf16 (in place allowed), res fp32.
+template <typename XT, typename YT>
+__global__ __launch_bounds__(256) void dropout_kernel(const XT* __restrict__ x, long long ldx, const float* __restrict__ res,
+                                                      long long ldres, YT* __restrict__ y, long long ldy, long long rows,
+                                                      int cols, Drop dr) {
+    const int c4n = cols >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * c4n) return;
+    const long long r = idx / c4n;
+    const int c = (int)(idx % c4n) * 4;
+    const float4 v = load4<XT>(x + r * ldx + c);
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = gn_keep(dr.seed, (unsigned)r, (unsigned)(c + j), dr.thresh) ? o[j] * dr.inv : 0.0f;
+    if (res) {
+        const float4 q = *reinterpret_cast<const float4*>(res + r * ldres + c);
+        o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w;
+    }
+    store4<YT>(y + r * ldy + c, o[0], o[1], o[2], o[3]);
+}
+
+hipError_t launch_dropout(const void* x, long long ldx, int x_lowp, const float* res, long long ldres, void* y, long long ldy,
+                          int y_lowp, long long rows, int cols, unsigned seed, unsigned thresh, hipStream_t st) {
+    if (rows == 0 || cols == 0) return hipSuccess;
+    if ((cols & 3) || (ldx & 3) || (ldy & 3) || (res && (ldres & 3))) return hipErrorInvalidValue;
+    Drop dr;
+    dr.seed = seed; dr.thresh = thresh; dr.inv = (float)(1.0 / (1.0 - (double)thresh / 4294967296.0));
+    const dim3 grid(gblocks(rows * (cols >> 2), 256)), block(256);
+    if (x_lowp && y_lowp) hipLaunchKernelGGL((dropout_kernel<__bf16, __bf16>), grid, block, 0, st, (const __bf16*)x, ldx, res, ldres, (__bf16*)y, ldy, rows, cols, dr);
+    else if (x_lowp) hipLaunchKernelGGL((dropout_kernel<__bf16, float>), grid, block, 0, st, (const __bf16*)x, ldx, res, ldres, (float*)y, ldy, rows, cols, dr);
+    else if (y_lowp) hipLaunchKernelGGL((dropout_kernel<float, __bf16>), grid, block, 0, st, (const float*)x, ldx, res, ldres, (__bf16*)y, ldy, rows, cols, dr);
+    else hipLaunchKernelGGL((dropout_kernel<float, float>), grid, block, 0, st, (const float*)x, ldx, res, ldres, (float*)y, ldy, rows, cols, dr);
+    return hipGetLastError();
+}
 hipError_t launch_slot_sum(const float* m, long long ldm, int C, const EdgeGraph& g, int S, float* out, long long ldo,
                            hipStream_t st) {
     if (g.N == 0) return hipSuccess;

@@ -589,10 +589,35 @@ def attention_lowp(mode: int, d_model: int, n_head: int) -> bool:
     return mode == MODE_BF16 and d_model % n_head == 0 and d_model // n_head in (32, 64)
 
 
-def attention_fwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor):
+def drop_thresh(p: float) -> int:
+    """Dropout rate -> 32-bit threshold of the counter-based keep rule (``include/graphnet_amd.h``: gn_dropout)."""
+    if not 0.0 <= p < 1.0:
+        raise ValueError("dropout rate must be in [0, 1)")
+    return min(int(round(p * 4294967296.0)), 4294967295)
+
+
+def dropout(x: Tensor, seed: int, thresh: int, res: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """``out = (res or 0) + dropout(x)`` with the stateless keep rule; applied to a gradient with the same seed it
+    is its own backward.  ``out=x`` works in place."""
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("x must be fp32 or bf16")
+    if res is not None:
+        _need(res, torch.float32, "res")
+    rows, cols = int(x.shape[0]), int(x.shape[1])
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float32 if res is not None else x.dtype, device=x.device)
+    with _timed("dropout"):
+        _lib.check(_lib.lib().gn_dropout(_p(x), _rows(x, "x"), int(x.dtype == torch.bfloat16), _p(res),
+                                         0 if res is None else _rows(res, "res"), _p(out), _rows(out, "out"),
+                                         int(out.dtype == torch.bfloat16), rows, cols, seed & 0xFFFFFFFF, thresh, _st()))
+    return out
+
+
+def attention_fwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, drop: Optional[Tuple[int, int]] = None):
     """``softmax(Q K^T / sqrt(dh)) V`` per head, every pulse attending to its own event (``gn_attention_fwd``).
     ``qkv`` ``[N, 3 d]`` (Q | K | V): fp32 -> exact-fp32 kernels, bf16 -> matrix-core kernels (dh 32 / 64);
-    ``plan`` from :func:`knn_plan`.  -> (out [N, d] in qkv's type, lse2 [N, H] fp32)."""
+    ``plan`` from :func:`knn_plan`; ``drop=(seed, thresh)``: dropout on the attention probabilities.
+    -> (out [N, d] in qkv's type, lse2 [N, H] fp32)."""
     if qkv.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("qkv must be fp32 or bf16")
     N, d3 = int(qkv.shape[0]), int(qkv.shape[1])
@@ -604,11 +629,13 @@ def attention_fwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor):
     lse2 = torch.empty((N, n_head), dtype=torch.float32, device=qkv.device)
     with _timed("attention_fwd"):
         _lib.check(_lib.lib().gn_attention_fwd(int(qkv.dtype == torch.bfloat16), _p(qkv), _rows(qkv, "qkv"), n_head,
-                                               d // n_head, _p(ptr), _p(plan), B, N, _p(out), d, _p(lse2), _st()))
+                                               d // n_head, _p(ptr), _p(plan), B, N, _p(out), d, _p(lse2),
+                                               (drop[0] & 0xFFFFFFFF) if drop else 0, drop[1] if drop else 0, _st()))
     return out, lse2
 
 
-def attention_bwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, out: Tensor, lse2: Tensor, dout: Tensor) -> Tensor:
+def attention_bwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, out: Tensor, lse2: Tensor, dout: Tensor,
+                  drop: Optional[Tuple[int, int]] = None) -> Tensor:
     """Gradient of :func:`attention_fwd` w.r.t. ``qkv`` -> [N, 3 d] in qkv's type (``out`` / ``dout`` likewise)."""
     _need(dout, qkv.dtype, "dout"); _need(out, qkv.dtype, "out")
     N, d3 = int(qkv.shape[0]), int(qkv.shape[1])
@@ -619,5 +646,6 @@ def attention_bwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, out: Tens
     with _timed("attention_bwd"):
         _lib.check(_lib.lib().gn_attention_bwd(int(qkv.dtype == torch.bfloat16), _p(qkv), _rows(qkv, "qkv"), n_head,
                                                d // n_head, _p(ptr), _p(plan), B, N, _p(out), _rows(out, "out"), _p(dout),
-                                               _rows(dout, "dout"), _p(lse2), _p(delta), _p(dqkv), d3, _st()))
+                                               _rows(dout, "dout"), _p(lse2), _p(delta), _p(dqkv), d3,
+                                               (drop[0] & 0xFFFFFFFF) if drop else 0, drop[1] if drop else 0, _st()))
     return dqkv

@@ -11,9 +11,10 @@ What runs where
   * the transformer encoder layer: in/out projections and the 2048-wide FFN on the MFMA GEMM kernels with fused
     bias / relu / residual-accumulate epilogues, LayerNorms on the row kernels, and the attention itself on
     ``csrc/attn.hip`` — ragged, every pulse attends to its own event, no ``to_dense_batch`` padding.
-  * dropout: the reference builds ``TransformerEncoderLayer`` with torch's default ``dropout=0.1``; this backend has
-    no dropout kernel yet and refuses to train with a non-zero rate (``dropout=0.0`` is the constructor default
-    here; inference / eval is identical to the reference either way).
+  * dropout (``TransformerEncoderLayer``'s default 0.1, as in the reference): stateless counter-based keep rule
+    (``gn_dropout``), applied to the attention probabilities inside the attention kernels and to the three
+    element-wise sites by one small kernel; nothing is stored, the backward recomputes the decisions.  The random
+    stream differs from torch's Philox stream by construction (as it does between any two torch devices).
 """
 from __future__ import annotations
 
@@ -68,15 +69,26 @@ class _DynTransFunction(torch.autograd.Function):
         # --- TransformerEncoderLayer, norm_first=False
         lowp = ops.attention_lowp(mode, d, H)       # bf16 qkv / attention output, matrix-core attention kernels
         qkv = ops.linear_fwd(mode, _ksegs([(y0, d)]), _wt(mode, Win, [d]), 3 * d, bias=bin_.contiguous(), out_lowp=lowp)
-        att, lse2 = ops.attention_fwd(qkv, H, ptr, plan)
-        z1 = y0.clone()
-        ops.linear_fwd(mode, _ksegs([(att, d)]), _wt(mode, Wout, [d]), d, bias=bout.contiguous(), out=z1, accum=True)
+        drop = cfg.get("drop")                      # None, or (thresh, [seed_attn, seed_1, seed_ffn, seed_2])
+        th = drop[0] if drop else 0
+        att, lse2 = ops.attention_fwd(qkv, H, ptr, plan, drop=(drop[1][0], th) if drop else None)
+        if drop:                                    # x + dropout1(self_attn(x))
+            proj = ops.linear_fwd(mode, _ksegs([(att, d)]), _wt(mode, Wout, [d]), d, bias=bout.contiguous())
+            z1 = ops.dropout(proj, drop[1][1], th, res=y0)
+        else:
+            z1 = y0.clone()
+            ops.linear_fwd(mode, _ksegs([(att, d)]), _wt(mode, Wout, [d]), d, bias=bout.contiguous(), out=z1, accum=True)
         y1, st1 = ops.rownorm_act_fwd(z1, d, "identity", g1, be1)
         F = int(Wl1.shape[0])
         h = ops.linear_fwd(mode, _ksegs([(y1, d)]), _wt(mode, Wl1, [d]), F, bias=bl1.contiguous(), relu=True,
                            out_lowp=mode == ops.MODE_BF16)     # the 2048-wide hidden layer is stored in the operand type
-        z3 = y1.clone()
-        ops.linear_fwd(mode, _ksegs([(h, F)]), _wt(mode, Wl2, [F]), d, bias=bl2.contiguous(), out=z3, accum=True)
+        if drop:                                    # x + dropout2(linear2(dropout(relu(linear1(x)))))
+            ops.dropout(h, drop[1][2], th, out=h)
+            f = ops.linear_fwd(mode, _ksegs([(h, F)]), _wt(mode, Wl2, [F]), d, bias=bl2.contiguous())
+            z3 = ops.dropout(f, drop[1][3], th, res=y1)
+        else:
+            z3 = y1.clone()
+            ops.linear_fwd(mode, _ksegs([(h, F)]), _wt(mode, Wl2, [F]), d, bias=bl2.contiguous(), out=z3, accum=True)
         y2, st2 = ops.rownorm_act_fwd(z3, d, "identity", g2, be2)
         ctx.cfg, ctx.p = cfg, p
         ctx.saved = (xin, Fin, pre1, a1, z2, aux, residual, r, st0, y0, qkv, att, lse2, z1, st1, y1, h, z3, st2)
@@ -96,16 +108,22 @@ class _DynTransFunction(torch.autograd.Function):
         grads: List[Optional[Tensor]] = [None] * _DT_PARAMS
         gy = gy.contiguous().to(torch.float32)
         # norm2, FFN
+        drop = cfg.get("drop")
+        th = drop[0] if drop else 0
         dz3, grads[16], grads[17] = ops.rownorm_act_bwd(gy, z3, d, "identity", g2, be2, st2)
-        grads[12], grads[13] = ops.linear_wgrad(mode, dz3, d, _ksegs([(h, F)]), with_bias=True)
-        dh = ops.linear_fwd(mode, _ksegs([(dz3, d)]), _wt(mode, Wl2.t(), [d]), F, gate=h, out_lowp=h.dtype == torch.bfloat16)
+        df = ops.dropout(dz3, drop[1][3], th) if drop else dz3
+        grads[12], grads[13] = ops.linear_wgrad(mode, df, d, _ksegs([(h, F)]), with_bias=True)
+        dh = ops.linear_fwd(mode, _ksegs([(df, d)]), _wt(mode, Wl2.t(), [d]), F, gate=h, out_lowp=h.dtype == torch.bfloat16)
+        if drop:                # dropped hidden units are 0 in h (gate closed); the kept ones carry the 1/(1-p)
+            ops.dropout(dh, drop[1][2], th, out=dh)
         grads[10], grads[11] = ops.linear_wgrad(mode, dh, F, _ksegs([(y1, d)]), with_bias=True)
         ops.linear_fwd(mode, _ksegs([(dh, F)]), _wt(mode, Wl1.t(), [F]), d, out=dz3, accum=True)      # dy1
         # norm1, attention
         dz1, grads[14], grads[15] = ops.rownorm_act_bwd(dz3, z1, d, "identity", g1, be1, st1)
-        grads[8], grads[9] = ops.linear_wgrad(mode, dz1, d, _ksegs([(att, d)]), with_bias=True)
-        datt = ops.linear_fwd(mode, _ksegs([(dz1, d)]), _wt(mode, Wout.t(), [d]), d, out_lowp=qkv.dtype == torch.bfloat16)
-        dqkv = ops.attention_bwd(qkv, H, ptr, plan, att, lse2, datt)
+        dproj = ops.dropout(dz1, drop[1][1], th) if drop else dz1
+        grads[8], grads[9] = ops.linear_wgrad(mode, dproj, d, _ksegs([(att, d)]), with_bias=True)
+        datt = ops.linear_fwd(mode, _ksegs([(dproj, d)]), _wt(mode, Wout.t(), [d]), d, out_lowp=qkv.dtype == torch.bfloat16)
+        dqkv = ops.attention_bwd(qkv, H, ptr, plan, att, lse2, datt, drop=(drop[1][0], th) if drop else None)
         grads[6], grads[7] = ops.linear_wgrad(mode, dqkv, 3 * d, _ksegs([(y0, d)]), with_bias=True)
         ops.linear_fwd(mode, _ksegs([(dqkv, 3 * d)]), _wt(mode, Win.t(), [3 * d]), d, out=dz1, accum=True)  # dy0
         # DynTrans.norm1
@@ -192,7 +210,7 @@ class DynTrans(torch.nn.Module):
     """Parameter holder + launcher of one ``DynTrans`` layer; attribute names as in ``layers.py:117-164``."""
 
     def __init__(self, layer_sizes: Optional[List[int]] = None, aggr: str = "max",
-                 features_subset: Any = None, n_head: int = 8, dropout: float = 0.0, **kwargs: Any):
+                 features_subset: Any = None, n_head: int = 8, dropout: float = 0.1, **kwargs: Any):
         super().__init__()
         if features_subset is None:
             features_subset = slice(None)
@@ -228,22 +246,28 @@ class DynTrans(torch.nn.Module):
                 e.norm1.weight, e.norm1.bias, e.norm2.weight, e.norm2.bias]
 
     def forward(self, x: Tensor, cfg: dict) -> Tensor:
+        cfg = dict(cfg, n_head=self._n_head)
         if self.training and self._dropout > 0.0:
-            raise NotImplementedError("graphnet_amd.DynTrans has no dropout kernel: construct with dropout=0.0 to "
-                                      "train, or call .eval(); there is no fallback")
-        return _DynTransFunction.apply(dict(cfg, n_head=self._n_head), x, *self.kernel_params())
+            # four independent streams per call: attention probabilities, dropout1, FFN dropout, dropout2
+            # (torch.nn.MultiheadAttention / TransformerEncoderLayer); seeds come from torch's CPU generator, so
+            # torch.manual_seed makes a run reproducible
+            seeds = torch.randint(0, 2 ** 31 - 1, (4,)).tolist()
+            cfg["drop"] = (ops.drop_thresh(self._dropout), seeds)
+            if cfg.get("seed_log") is not None:
+                cfg["seed_log"].append(seeds)
+        return _DynTransFunction.apply(cfg, x, *self.kernel_params())
 
 
 class DynEdgeTITO(GNN):
     """DynEdgeTITO (dynamical edge convolution with transformer) on MI355X.  Constructor as
-    ``dynedge_kaggle_tito.py:32-59`` plus ``dropout`` (see the module docstring)."""
+    ``dynedge_kaggle_tito.py:32-59`` plus ``dropout`` (the rate the reference gets from torch's default)."""
 
     def __init__(self, nb_inputs: int, features_subset: Optional[List[int]] = None,
                  dyntrans_layer_sizes: Optional[List[Tuple[int, ...]]] = None,
                  global_pooling_schemes: List[str] = ["max"], use_global_features: bool = True,
                  use_post_processing_layers: bool = True, post_processing_layer_sizes: Optional[List[int]] = None,
                  readout_layer_sizes: Optional[List[int]] = None, n_head: int = 8, nb_neighbours: int = 8,
-                 dropout: float = 0.0):
+                 dropout: float = 0.1):
         if dyntrans_layer_sizes is None:
             dyntrans_layer_sizes = [(256, 256)] * 4
         assert isinstance(dyntrans_layer_sizes, list) and len(dyntrans_layer_sizes)
@@ -323,7 +347,9 @@ class DynEdgeTITO(GNN):
                 ops.knn_graph(x, self._graph_columns, batch32, ptr32, self._nb_neighbours, strict=self._knn_strict)
         plan = ops.knn_plan(ptr32, N)
         gv = ops.graph_globals(x, ptr32, table, n_pulses) if self._use_global_features else None
-        cfg = {"mode": self._compute_mode, "graph": table, "ptr": ptr32, "batch": batch32, "plan": plan}
+        seed_log: List[List[int]] = []
+        cfg = {"mode": self._compute_mode, "graph": table, "ptr": ptr32, "batch": batch32, "plan": plan,
+               "seed_log": seed_log if return_trace else None}
         conv_out = []
         for conv in self._conv_layers:
             x = conv(x, cfg)
@@ -340,5 +366,5 @@ class DynEdgeTITO(GNN):
         out = self._readout(out)
         if return_trace:
             return out, {"conv_out": conv_out, "post": pcfg.get("post"), "pooled": pooled, "global_variables": gv,
-                         "graph": table}
+                         "graph": table, "dropout_seeds": seed_log}
         return out

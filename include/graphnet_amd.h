@@ -217,12 +217,24 @@ int gn_segment_pool_bwd(const float* gout, int32_t C, const int32_t* ptr, const 
  * gradient w.r.t. qkv given dout; delta[N, H] fp32 is scratch.
  * lowp = 0: qkv / out / dout / dqkv are fp32, exact-fp32 kernels on the vector ALU, DH in {8, 16, 32, 64}.
  * lowp = 1: those four tensors are bf16, products on the matrix core (fp32 softmax statistics and accumulation),
- *           DH in {32, 64}. */
+ *           DH in {32, 64}.
+ * drop_thresh != 0: dropout on the attention probabilities (see gn_dropout for the rule). */
 int gn_attention_fwd(int32_t lowp, const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr,
-                     const int32_t* tile_ptr, int32_t B, int32_t N, void* out, int64_t ldo, float* lse2, void* stream);
+                     const int32_t* tile_ptr, int32_t B, int32_t N, void* out, int64_t ldo, float* lse2, uint32_t drop_seed,
+                     uint32_t drop_thresh, void* stream);
 int gn_attention_bwd(int32_t lowp, const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr,
                      const int32_t* tile_ptr, int32_t B, int32_t N, const void* out, int64_t ldo, const void* dout,
-                     int64_t lddo, const float* lse2, float* delta, void* dqkv, int64_t lddq, void* stream);
+                     int64_t lddo, const float* lse2, float* delta, void* dqkv, int64_t lddq, uint32_t drop_seed,
+                     uint32_t drop_thresh, void* stream);
+
+/* ---- dropout (torch.nn.Dropout inside TransformerEncoderLayer / MultiheadAttention, layers.py:149-160) ---- */
+/* Counter-based: element (r, c) of stream `seed` is kept iff mix32(mix32(seed ^ r*0x9E3779B1) ^ c*0x85EBCA77) >=
+ * thresh, thresh = round(p * 2^32), kept values are scaled by 1 / (1 - thresh / 2^32); nothing is stored, the
+ * backward recomputes the decisions from the same seed (apply gn_dropout to the gradient).  thresh = 0 disables.
+ * y[r, c] = (res ? res[r, c] : 0) + dropout(x)[r, c]; x / y fp32 or bf16 (in place allowed), res fp32.
+ * The attention kernels drop the softmax probabilities with r = query row, c = key row * H + head. */
+int gn_dropout(const void* x, int64_t ldx, int32_t x_lowp, const float* res, int64_t ldres, void* y, int64_t ldy,
+               int32_t y_lowp, int64_t rows, int32_t cols, uint32_t seed, uint32_t thresh, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ from __future__ import annotations
 import math
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 from torch import Tensor
 
@@ -38,6 +39,35 @@ def edge_conv_tito(x: Tensor, edge_index: Tensor, nn: torch.nn.Module, aggr: str
 
 
 # --------------------------------------------------------------------------------------
+# dropout with an explicit keep rule.  torch's own dropout draws from a Philox stream that no other
+# implementation reproduces; the HIP backend uses a stateless hash (include/graphnet_amd.h: gn_dropout) and this
+# is its integer-exact numpy replica, so that training-mode parity can be checked with identical masks.
+# --------------------------------------------------------------------------------------
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _mix32(x: np.ndarray) -> np.ndarray:
+    x = x & _M32
+    x = x ^ (x >> np.uint64(16)); x = (x * np.uint64(0x21F0AAAD)) & _M32
+    x = x ^ (x >> np.uint64(15)); x = (x * np.uint64(0x735A2D97)) & _M32
+    return x ^ (x >> np.uint64(15))
+
+
+def keep_mask(seed: int, a: np.ndarray, b: np.ndarray, thresh: int) -> np.ndarray:
+    """keep[a, b] = mix32(mix32(seed ^ a*0x9E3779B1) ^ b*0x85EBCA77) >= thresh  (uint32 arithmetic)."""
+    a = np.asarray(a, dtype=np.uint64); b = np.asarray(b, dtype=np.uint64)
+    h = _mix32(np.uint64(seed & 0xFFFFFFFF) ^ ((a * np.uint64(0x9E3779B1)) & _M32))
+    return _mix32(h ^ ((b * np.uint64(0x85EBCA77)) & _M32)) >= np.uint64(thresh)
+
+
+def dropout_rc(x: Tensor, seed: int, thresh: int) -> Tensor:
+    """Element (row, col) kept by the rule above, kept values scaled by 1 / (1 - thresh / 2^32)."""
+    r = np.arange(x.shape[0])[:, None]; c = np.arange(x.shape[1])[None, :]
+    inv = 1.0 / (1.0 - thresh / 4294967296.0)
+    return x * torch.from_numpy(keep_mask(seed, r, c, thresh).astype(np.float32) * np.float32(inv))
+
+
+# --------------------------------------------------------------------------------------
 # one post-norm encoder layer on ragged events (layers.py:166-197 -> torch.nn.TransformerEncoderLayer)
 # --------------------------------------------------------------------------------------
 def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
@@ -47,7 +77,7 @@ def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
 
 
 def self_attention_ragged(x: Tensor, ptr: Sequence[int], in_w: Tensor, in_b: Tensor, out_w: Tensor, out_b: Tensor,
-                          n_head: int) -> Tensor:
+                          n_head: int, drop: Optional[Tuple[int, int]] = None) -> Tensor:
     """Multi-head self attention where every event attends to its own pulses only: what the padded
     ``[B, Lmax, d]`` tensor + key-padding mask computes for the rows that survive ``x[mask]``."""
     N, d = x.shape
@@ -63,18 +93,35 @@ def self_attention_ragged(x: Tensor, ptr: Sequence[int], in_w: Tensor, in_b: Ten
         ve = v[a:b].reshape(n, n_head, dh).transpose(0, 1)
         s = (qe @ ke.transpose(1, 2)) / math.sqrt(dh)               # [H, n, n]
         p = torch.softmax(s, dim=-1)
+        if drop is not None:            # MultiheadAttention's dropout on the probabilities: (query, key * H + head)
+            seed, thresh = drop
+            qg = np.arange(a, b)[None, :, None]
+            kg = np.arange(a, b)[None, None, :]
+            hd = np.arange(n_head)[:, None, None]
+            keep = keep_mask(seed, qg, kg * n_head + hd, thresh)
+            p = p * torch.from_numpy(keep.astype(np.float32) * np.float32(1.0 / (1.0 - thresh / 4294967296.0)))
         outs.append((p @ ve).transpose(0, 1).reshape(n, d))
     o = torch.cat(outs, dim=0) if outs else x.new_zeros((0, d))
     return o @ out_w.t() + out_b
 
 
-def encoder_layer_ragged(x: Tensor, ptr: Sequence[int], layer: torch.nn.TransformerEncoderLayer) -> Tensor:
-    """norm_first=False, activation relu, dropout inactive (eval, or p = 0)."""
+def encoder_layer_ragged(x: Tensor, ptr: Sequence[int], layer: torch.nn.TransformerEncoderLayer,
+                         drop: Optional[Tuple[int, Sequence[int]]] = None) -> Tensor:
+    """norm_first=False, activation relu.  ``drop=None``: dropout inactive (eval, or p = 0); ``drop=(thresh,
+    [seed_attn, seed_1, seed_ffn, seed_2])``: the four dropout sites of torch's layer with explicit masks."""
     sa = layer.self_attn
+    th = drop[0] if drop else 0
     a = self_attention_ragged(x, ptr, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
-                              sa.num_heads)
+                              sa.num_heads, drop=(drop[1][0], th) if drop else None)
+    if drop:
+        a = dropout_rc(a, drop[1][1], th)
     x = layer_norm(x + a, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-    f = torch.relu(x @ layer.linear1.weight.t() + layer.linear1.bias) @ layer.linear2.weight.t() + layer.linear2.bias
+    hdn = torch.relu(x @ layer.linear1.weight.t() + layer.linear1.bias)
+    if drop:
+        hdn = dropout_rc(hdn, drop[1][2], th)
+    f = hdn @ layer.linear2.weight.t() + layer.linear2.bias
+    if drop:
+        f = dropout_rc(f, drop[1][3], th)
     return layer_norm(x + f, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
 
 
@@ -96,11 +143,11 @@ class DynTransOracle(torch.nn.Module):
                                                dropout=dropout)
         self._transformer_encoder = torch.nn.TransformerEncoder(enc, num_layers=1)
 
-    def forward(self, x: Tensor, edge_index: Tensor, ptr: Sequence[int]) -> Tensor:
+    def forward(self, x: Tensor, edge_index: Tensor, ptr: Sequence[int], drop=None) -> Tensor:
         x_out = edge_conv_tito(x, edge_index, self.nn)
         x = x + x_out if x_out.shape[-1] == x.shape[-1] else x_out
         x = layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        return encoder_layer_ragged(x, ptr, self._transformer_encoder.layers[0])
+        return encoder_layer_ragged(x, ptr, self._transformer_encoder.layers[0], drop=drop)
 
 
 class DynEdgeTITOOracle(torch.nn.Module):
@@ -138,7 +185,9 @@ class DynEdgeTITOOracle(torch.nn.Module):
             mods += [torch.nn.Linear(a, b), act]
         self._readout = torch.nn.Sequential(*mods)
 
-    def forward(self, x: Tensor, edge_index: Tensor, batch: Tensor, n_pulses: Tensor, return_trace: bool = False):
+    def forward(self, x: Tensor, edge_index: Tensor, batch: Tensor, n_pulses: Tensor, return_trace: bool = False,
+                drop: Optional[Tuple[int, Sequence[Sequence[int]]]] = None):
+        """``drop=(thresh, seeds_per_layer)`` replays a training step of the HIP backend with its dropout masks."""
         B = int(n_pulses.shape[0])
         ptr = [0] + torch.cumsum(torch.bincount(batch, minlength=B), 0).tolist()
         trace = {}
@@ -148,8 +197,8 @@ class DynEdgeTITOOracle(torch.nn.Module):
                             torch.log10(n_pulses).to(torch.float32).unsqueeze(1)], dim=1)
             trace["global_variables"] = gv
         trace["conv_out"] = []
-        for conv in self._conv_layers:
-            x = conv(x, edge_index, ptr)
+        for l, conv in enumerate(self._conv_layers):
+            x = conv(x, edge_index, ptr, drop=(drop[0], drop[1][l]) if drop else None)
             trace["conv_out"].append(x)
         if self._use_post:
             x = self._post_processing(x)

@@ -23,8 +23,11 @@ def norm_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def _ragged_attention_reference(qkv: torch.Tensor, ptr, H: int) -> torch.Tensor:
-    """fp64 restatement of the attention core of ``tito_oracle.self_attention_ragged`` (no projections)."""
+def _ragged_attention_reference(qkv: torch.Tensor, ptr, H: int, drop=None) -> torch.Tensor:
+    """fp64 restatement of the attention core of ``tito_oracle.self_attention_ragged`` (no projections);
+    ``drop=(seed, thresh)``: dropout on the probabilities with the oracle's replica of the keep rule."""
+    import numpy as np
+    from oracle import tito_oracle
     N, d3 = qkv.shape
     d = d3 // 3
     dh = d // H
@@ -37,12 +40,17 @@ def _ragged_attention_reference(qkv: torch.Tensor, ptr, H: int) -> torch.Tensor:
         ke = k[a:b].reshape(n, H, dh).transpose(0, 1)
         ve = v[a:b].reshape(n, H, dh).transpose(0, 1)
         p = torch.softmax(qe @ ke.transpose(1, 2) / math.sqrt(dh), dim=-1)
+        if drop is not None:
+            keep = tito_oracle.keep_mask(drop[0], np.arange(a, b)[None, :, None],
+                                         np.arange(a, b)[None, None, :] * H + np.arange(H)[:, None, None], drop[1])
+            p = p * torch.from_numpy(keep.astype(np.float64) / (1.0 - drop[1] / 4294967296.0))
         outs.append((p @ ve).transpose(0, 1).reshape(n, d))
     return torch.cat(outs, 0)
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
 @pytest.mark.parametrize("H,dh", [(8, 32), (4, 16), (8, 8), (2, 64)])
-def test_ragged_attention_forward_backward(H, dh):
+def test_ragged_attention_forward_backward(H, dh, p_drop):
     """Events of 1, 63, 64, 65, 200 and 1300 pulses (tile tails, single-key softmax, a multi-tile event)."""
     from graphnet_amd import ops
     torch.manual_seed(H * 100 + dh)
@@ -53,15 +61,16 @@ def test_ragged_attention_forward_backward(H, dh):
     N, d = ptr[-1], H * dh
     qkv = torch.randn(N, 3 * d, dtype=torch.float64) * 1.5
     qkv.requires_grad_(True)
-    want = _ragged_attention_reference(qkv, ptr, H)
+    drop = (987654321 + H, ops.drop_thresh(p_drop)) if p_drop > 0 else None
+    want = _ragged_attention_reference(qkv, ptr, H, drop)
     w = torch.randn(N, d, dtype=torch.float64)
     (want * w).sum().backward()
     ptr_d = torch.tensor(ptr, dtype=torch.int32, device=DEV)
     plan = ops.knn_plan(ptr_d, N)
     x = qkv.detach().float().to(DEV)
-    out, lse2 = ops.attention_fwd(x, H, ptr_d, plan)
+    out, lse2 = ops.attention_fwd(x, H, ptr_d, plan, drop=drop)
     assert rel_err(out, want.detach()) < 1e-5          # fp32 flash accumulation against fp64
-    dqkv = ops.attention_bwd(x, H, ptr_d, plan, out, lse2, w.float().to(DEV))
+    dqkv = ops.attention_bwd(x, H, ptr_d, plan, out, lse2, w.float().to(DEV), drop=drop)
     for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
         assert rel_err(dqkv[:, sl], qkv.grad[:, sl]) < 2e-5, name
     # bf16 tensors: matrix-core kernels for head widths 32 / 64.  Q, K, V, P, dS and the outputs are rounded to
@@ -69,12 +78,12 @@ def test_ragged_attention_forward_backward(H, dh):
     if dh in (32, 64):
         xb = x.to(torch.bfloat16)
         ref = xb.double().cpu().requires_grad_(True)            # reference on the SAME (rounded) inputs
-        want_b = _ragged_attention_reference(ref, ptr, H)
+        want_b = _ragged_attention_reference(ref, ptr, H, drop)
         (want_b * w).sum().backward()
-        out1, lse1 = ops.attention_fwd(xb, H, ptr_d, plan)
+        out1, lse1 = ops.attention_fwd(xb, H, ptr_d, plan, drop=drop)
         assert out1.dtype == torch.bfloat16
         assert rel_err(out1, want_b.detach()) < 2e-2
-        dqkv1 = ops.attention_bwd(xb, H, ptr_d, plan, out1, lse1, w.to(torch.bfloat16).to(DEV))
+        dqkv1 = ops.attention_bwd(xb, H, ptr_d, plan, out1, lse1, w.to(torch.bfloat16).to(DEV), drop=drop)
         for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
             assert rel_err(dqkv1[:, sl], ref.grad[:, sl]) < 3e-2, name
             assert norm_err(dqkv1[:, sl], ref.grad[:, sl]) < 1.5e-2, name
@@ -91,19 +100,20 @@ def test_ragged_attention_rejects_unsupported_head_width():
         ops.attention_fwd(torch.zeros(4, 3 * 24, device=DEV), 2, ptr_d, plan)
 
 
-def _tito_pair(name, seed=11, **kw):
+def _tito_pair(name, seed=11, dropout=0.0, **kw):
     import graphnet_amd as g
     from oracle import tito_oracle
     torch.manual_seed(seed)
     ref = tito_oracle.DynEdgeTITOOracle(7, **kw).eval()
-    m = g.DynEdgeTITO(7, **kw)
+    m = g.DynEdgeTITO(7, dropout=dropout, **kw)
     m.load_state_dict(ref.state_dict())
     m.to(DEV).set_backend(dtype=name)
     return m, ref
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
 @pytest.mark.parametrize("name,mode,tol", [("fp32", 0, 1e-4), ("bf16", 1, 3e-2)])
-def test_dynedge_tito_forward_backward(oracle, name, mode, tol):
+def test_dynedge_tito_forward_backward(oracle, name, mode, tol, dropout):
     """DynEdgeTITO (dynedge_kaggle_tito.py:236-268): two DynTrans layers (first without, second with the residual),
     post MLP, max + mean pooling, globals, read-out.  Output, per-layer activations and every gradient (edge
     MLP, LayerNorms, attention in/out projections, FFN, post MLP, read-out) against the oracle on the same edges."""
@@ -112,14 +122,18 @@ def test_dynedge_tito_forward_backward(oracle, name, mode, tol):
     b.x[3:16, :3] = b.x[2, :3]          # duplicate positions: overflow rows in the neighbour table
     kw = dict(dyntrans_layer_sizes=[(64, 64), (64, 64)], post_processing_layer_sizes=[48, 32],
               readout_layer_sizes=[32, 16], global_pooling_schemes=["max", "mean"], n_head=4)
-    m, ref = _tito_pair(name, **kw)
+    m, ref = _tito_pair(name, dropout=dropout, **kw)
     ei = oracle.knn_graph(b.x, 8, b.batch, [0, 1, 2])
-    yo, tro = ref(b.x, ei, b.batch, b.n_pulses, return_trace=True)
-    w = torch.randn(yo.shape, generator=torch.Generator().manual_seed(2))
-    (yo * w).sum().backward()
-    m.train()
+    m.train()                       # training mode: with dropout > 0 the four dropout sites of every layer are live
     y, tr = m(b.to(DEV), return_trace=True)
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
     (y * w.to(DEV)).sum().backward()
+    from graphnet_amd import ops
+    drop = (ops.drop_thresh(dropout), tr["dropout_seeds"]) if dropout > 0 else None
+    assert len(tr["dropout_seeds"]) == (2 if dropout > 0 else 0)
+    b = b.to("cpu")
+    yo, tro = ref(b.x, ei, b.batch, b.n_pulses, return_trace=True, drop=drop)   # same keep decisions, replayed
+    (yo * w).sum().backward()
     assert torch.equal(tr["graph"].edge_index().cpu(), ei)           # device-built layer-1 graph, bit-exact
     for l, (a, ao) in enumerate(zip(tr["conv_out"], tro["conv_out"])):
         assert rel_err(a, ao.detach()) < tol, f"{name}: DynTrans layer {l}"
@@ -134,14 +148,46 @@ def test_dynedge_tito_forward_backward(oracle, name, mode, tol):
             assert norm_err(p.grad, po.grad) < 1.2e-1, f"{name}: grad {kn}"
 
 
-def test_dynedge_tito_state_dict_and_dropout_guard():
+def test_dynedge_tito_state_dict_and_eval_mode():
     import graphnet_amd as g
     from oracle import tito_oracle
     kw = dict(dyntrans_layer_sizes=[(32, 32)], post_processing_layer_sizes=[32], readout_layer_sizes=[16], n_head=4)
     assert list(g.DynEdgeTITO(7, **kw).state_dict()) == list(tito_oracle.DynEdgeTITOOracle(7, **kw).state_dict())
     from graphnet_amd.synthetic import synthetic_icecube86_batch
     b = synthetic_icecube86_batch(3, seed=1).to(DEV)
-    m = g.DynEdgeTITO(7, dropout=0.1, **kw).to(DEV)
-    with pytest.raises(NotImplementedError, match="dropout"):
-        m.train()(b)
-    assert m.eval()(b).shape == (3, 16)
+    m = g.DynEdgeTITO(7, **kw).to(DEV)            # default dropout 0.1, as the reference gets from torch
+    y_eval = m.eval()(b)
+    assert y_eval.shape == (3, 16) and torch.equal(y_eval, m(b))            # eval: deterministic, no dropout
+    torch.manual_seed(5)
+    y1 = m.train()(b)
+    torch.manual_seed(5)
+    y2 = m(b)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y_eval)              # train: seeded by torch's generator
+    assert not torch.equal(m(b), y1)
+
+
+def test_dropout_kernel_statistics_and_replica():
+    """gn_dropout: keep rate, scaling, residual add, in-place bf16, and bit equality with the numpy replica the
+    oracle uses (``tito_oracle.keep_mask``)."""
+    from graphnet_amd import ops
+    from oracle import tito_oracle
+    import numpy as np
+    torch.manual_seed(0)
+    x = torch.randn(1000, 256, device=DEV)
+    res = torch.randn(1000, 256, device=DEV)
+    th = ops.drop_thresh(0.1)
+    y = ops.dropout(x, 12345, th)
+    keep = tito_oracle.keep_mask(12345, np.arange(1000)[:, None], np.arange(256)[None, :], th)
+    assert abs(keep.mean() - 0.9) < 5e-3
+    inv = 1.0 / (1.0 - th / 4294967296.0)
+    want = x.cpu() * torch.from_numpy(keep.astype(np.float32) * np.float32(inv))
+    assert torch.allclose(y.cpu(), want, rtol=1e-6, atol=0)
+    assert torch.equal((y != 0).cpu(), torch.from_numpy(keep) & (x.cpu() != 0))
+    y2 = ops.dropout(x, 12345, th, res=res)
+    assert torch.allclose(y2.cpu(), want + res.cpu(), rtol=1e-6, atol=1e-6)
+    xb = x.to(torch.bfloat16)
+    yb = ops.dropout(xb.clone(), 7, th, out=None)
+    xc = xb.clone()
+    ops.dropout(xc, 7, th, out=xc)
+    assert torch.equal(xc, yb)
+    assert not torch.equal(ops.dropout(x, 1, th), y)

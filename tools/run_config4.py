@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[3]: DynEdgeTITO (EdgeConvTito + transformer encoder per layer, default sizes: 4 x (256, 256),
 8 heads, FFN 2048), mixed 50-3000 pulses/event (log-uniform), k=8 static edges.  Times fwd+bwd+Adam.
-usage: run_config4.py [B] [fp32|bf16] [steps]"""
+usage: run_config4.py [B] [fp32|bf16] [steps] [--dropout P] [--cpu-baseline]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import graphnet_amd as g
@@ -10,11 +10,12 @@ from graphnet_amd.synthetic import synthetic_icecube86_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 steps = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 5
+p_drop = float(sys.argv[sys.argv.index("--dropout") + 1]) if "--dropout" in sys.argv else 0.1   # torch / reference default
 torch.manual_seed(0)
 b = synthetic_icecube86_batch(B, seed=5, count_range=(50, 3000)).to("cuda")
 m = g.StandardModel(
     graph_definition=g.KNNGraph(g.IceCube86(), nb_nearest_neighbours=8),
-    backbone=g.DynEdgeTITO(7, global_pooling_schemes=["max"]),
+    backbone=g.DynEdgeTITO(7, global_pooling_schemes=["max"], dropout=p_drop),
     tasks=[g.EnergyReconstruction(hidden_size=128, loss_function=g.LogCoshLoss(),
                                   transform_prediction_and_target=torch.log10)],
     optimizer_kwargs={"lr": 1e-4, "eps": 1e-3},
@@ -35,7 +36,7 @@ for _ in range(steps): l = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 n = b.n_pulses.double()
-print(f"config4 B={B} N={b.x.shape[0]} (pulses/event {int(n.min())}..{int(n.max())}, sum n^2 = {float((n*n).sum()):.3g}) {dtype}: "
+print(f"config4 dropout={p_drop} B={B} N={b.x.shape[0]} (pulses/event {int(n.min())}..{int(n.max())}, sum n^2 = {float((n*n).sum()):.3g}) {dtype}: "
       f"{1e3*dt:.1f} ms/step  {B/dt:.1f} events/s  {b.x.shape[0]/dt/1e6:.2f} Mpulses/s  loss {float(l):.4f}")
 print({k: round(ms / steps, 3) for k, (n_, ms) in ops.timer_summary().items()})
 if "--cpu-baseline" in sys.argv:     # the oracle (CPU restatement, test infrastructure) timed on a bounded sample
