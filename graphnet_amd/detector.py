@@ -11,6 +11,8 @@ from typing import Callable, Dict, List, Sequence, Tuple
 import torch
 from torch import Tensor
 
+from .model import Model
+
 
 # A standardisation is a short program of (op, constant) steps applied left to right in fp32 - the same
 # expression, operation by operation, as the reference's lambdas (``x / 500.0`` is a division, never a
@@ -36,8 +38,9 @@ def _apply_ops(x: Tensor, prog: Sequence[Op]) -> Tensor:
     return x
 
 
-class Detector:
-    """Base class: ``detector(input_features, input_feature_names) -> standardized tensor``."""
+class Detector(Model):
+    """Base class: ``detector(input_features, input_feature_names) -> standardized tensor`` (a ``Model``, as in
+    the reference, so that it appears in ``ModelConfig`` files by class name)."""
 
     xyz: List[str] = []
     string_id_column = "string"
@@ -50,10 +53,8 @@ class Detector:
     def feature_map(self) -> Dict[str, Callable[[Tensor], Tensor]]:
         return {k: (lambda x, p=tuple(v): _apply_ops(x, p)) for k, v in self.feature_ops().items()}
 
-    def __call__(self, input_features: Tensor, input_feature_names: List[str]) -> Tensor:
+    def forward(self, input_features: Tensor, input_feature_names: List[str]) -> Tensor:
         return self._standardize(input_features, input_feature_names)
-
-    forward = __call__
 
     def _standardize(self, input_features: Tensor, input_feature_names: List[str]) -> Tensor:
         """In place, column by column (``detector.py:64-77``).  A HIP tensor is standardised by one kernel

@@ -18,15 +18,61 @@ import yaml
 _REGISTRY: Dict[str, type] = {}
 
 
+# Strings the reference's YAML uses for things YAML cannot hold (``utilities/config/parsing.py``): classes as
+# ``"!class <module> <name>"``, callables as ``"!lambda <source>"``.  The reference evaluates the lambda source; here
+# only the expressions that occur in the reference's shipped configs are recognised, nothing is ever evaluated.
+def _pow10(x: Any) -> Any:
+    return torch.pow(10, x)
+
+
+def _identity(x: Any) -> Any:
+    return x
+
+
+_KNOWN_LAMBDAS = {
+    "x: torch.log10(x)": torch.log10,
+    "x: torch.pow(10,x)": _pow10,
+    "x: torch.pow(10, x)": _pow10,
+    "x: 10**x": _pow10,
+    "x: x": _identity,
+}
+_CLASS_MODULES = ("torch.optim", "torch.optim.lr_scheduler", "torch.optim.adam", "torch.optim.adamw", "torch.optim.sgd")
+_LAMBDA_NAMES = {torch.log10: "x: torch.log10(x)", _pow10: "x: torch.pow(10,x)", _identity: "x: x"}
+
+
+def _parse_special_string(v: str) -> Any:
+    if v.startswith("!class "):
+        _, module, name = v.split()
+        if name in _REGISTRY:
+            return _REGISTRY[name]
+        if module in _CLASS_MODULES or module.startswith("torch.optim"):
+            import importlib
+            return getattr(importlib.import_module(module), name)
+        raise ValueError(f"config names class {module}.{name}: only torch.optim classes and graphnet_amd models are resolved")
+    if v.startswith("!lambda "):
+        src = v[len("!lambda "):].strip()
+        if src in _KNOWN_LAMBDAS:
+            return _KNOWN_LAMBDAS[src]
+        raise ValueError(f"config holds the lambda {src!r}: graphnet_amd never evaluates source text from a config; "
+                         "pass the callable to the constructor instead")
+    if v.startswith("torch.") and hasattr(torch, v[6:]) and isinstance(getattr(torch, v[6:]), torch.dtype):
+        return getattr(torch, v[6:])
+    return v
+
+
 def _to_config_value(v: Any) -> Any:
     if isinstance(v, Model):
-        return v.config.as_dict()
+        return {"ModelConfig": v.config.as_dict()}
     if isinstance(v, (list, tuple)):
         return [_to_config_value(i) for i in v]
     if isinstance(v, slice):
         return {"__slice__": [v.start, v.stop, v.step]}
     if isinstance(v, type):
-        return {"__class__": f"{v.__module__}.{v.__qualname__}"}
+        return f"!class {v.__module__} {v.__qualname__}"
+    if isinstance(v, torch.dtype):
+        return str(v)
+    if callable(v) and v in _LAMBDA_NAMES:
+        return "!lambda " + _LAMBDA_NAMES[v]
     if isinstance(v, dict):
         return {k: _to_config_value(i) for k, i in v.items()}
     if isinstance(v, (int, float, str, bool)) or v is None:
@@ -59,6 +105,10 @@ class ModelConfig:
 
     @staticmethod
     def _from_value(v: Any) -> Any:
+        if isinstance(v, dict) and set(v) == {"ModelConfig"}:          # the reference's nesting (model_config.py:249-262)
+            v = v["ModelConfig"]
+        if isinstance(v, str):
+            return _parse_special_string(v)
         if isinstance(v, dict) and set(v) == {"class_name", "arguments"}:
             return ModelConfig(v["class_name"], v["arguments"]).construct()
         if isinstance(v, dict) and set(v) == {"__slice__"}:
@@ -72,8 +122,13 @@ class ModelConfig:
     def construct(self) -> "Model":
         """Rebuild by bare class name (``utilities/config/parsing.py:57-73`` looks classes up
         by name across the package; here every ``Model`` subclass registers itself)."""
+        if self.class_name not in _REGISTRY:
+            raise KeyError(f"graphnet_amd has no class named {self.class_name!r} (known: {sorted(_REGISTRY)})")
         klass = _REGISTRY[self.class_name]
         args = {k: self._from_value(v) for k, v in self.arguments.items()}
+        accepted = inspect.signature(klass.__init__).parameters
+        if not any(p.kind == inspect.Parameter.VAR_KEYWORD for p in accepted.values()):
+            args = {k: v for k, v in args.items() if k in accepted}     # e.g. KNNGraph(dtype=..., ...) extras
         # YAML has no tuples: dynedge_layer_sizes is a list of tuples in the ctor contract
         if "dynedge_layer_sizes" in args and args["dynedge_layer_sizes"] is not None:
             args["dynedge_layer_sizes"] = [tuple(s) for s in args["dynedge_layer_sizes"]]
@@ -89,8 +144,12 @@ class _ConfigSaverMeta(type):
             sig = inspect.signature(cls.__init__)
             bound = sig.bind(obj, *args, **kwargs)
             bound.apply_defaults()
-            arguments = OrderedDict((k, v) for k, v in bound.arguments.items() if k != "self")
-            arguments.pop("kwargs", None)
+            var = {n for n, prm in sig.parameters.items()
+                   if prm.kind in (inspect.Parameter.VAR_POSITIONAL, inspect.Parameter.VAR_KEYWORD)}
+            arguments = OrderedDict((k, v) for k, v in bound.arguments.items() if k != "self" and k not in var)
+            for n in var:                                  # **kwargs that were actually passed are arguments too
+                if isinstance(bound.arguments.get(n), dict):
+                    arguments.update(bound.arguments[n])
         except TypeError:
             arguments = OrderedDict(kwargs)
         obj._config = ModelConfig(cls.__name__, dict(arguments))

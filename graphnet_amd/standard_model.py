@@ -64,6 +64,72 @@ class LogCoshLoss(LossFunction):
 
 
 # ------------------------------------------------------------------------------ tasks
+class BinaryCrossEntropyLoss(LossFunction):
+    """``training/loss_functions.py:198-208``: predictions are probabilities, targets 0 / 1."""
+
+    def _forward(self, prediction: Tensor, target: Tensor) -> Tensor:
+        return torch.nn.functional.binary_cross_entropy(prediction.float(), target.float(), reduction="none")
+
+
+class VonMisesFisherLoss(LossFunction):
+    """von Mises-Fisher negative log-likelihood (``training/loss_functions.py:211-356``).  ``log C_m(kappa)`` is
+    written in closed form for the two dimensions the reference has losses for (m = 2: modified Bessel I0 through
+    ``torch.special.i0e``; m = 3: ``log k - log sinh k - log 4 pi``), differentiable by autograd, finite for every
+    kappa; the switch to the [1812.04616] Sec. 8.2 approximation above ``kappa_switch`` is kept as in the
+    reference so that losses agree number for number."""
+
+    @classmethod
+    def log_cmk_exact(cls, m: int, kappa: Tensor) -> Tensor:
+        k = kappa.double()
+        if m == 2:
+            out = -np.log(2 * np.pi) - (torch.log(torch.special.i0e(k)) + k)
+        elif m == 3:
+            out = torch.log(k) - k - torch.log(2 * np.pi * (-torch.expm1(-2 * k)))
+        else:
+            raise NotImplementedError("log C_m(kappa) is implemented for m = 2 and m = 3")
+        return out.type(kappa.dtype)
+
+    @classmethod
+    def log_cmk_approx(cls, m: int, kappa: Tensor) -> Tensor:
+        v = m / 2.0 - 0.5
+        a = torch.sqrt((v + 1) ** 2 + kappa ** 2)
+        b = v - 1
+        return -a + b * torch.log(b + a)
+
+    @classmethod
+    def log_cmk(cls, m: int, kappa: Tensor, kappa_switch: float = 100.0) -> Tensor:
+        ks = torch.tensor([kappa_switch], dtype=kappa.dtype, device=kappa.device)
+        mask_exact = kappa < ks
+        offset = cls.log_cmk_approx(m, ks) - cls.log_cmk_exact(m, ks)
+        ret = cls.log_cmk_approx(m, kappa) - offset
+        return torch.where(mask_exact, cls.log_cmk_exact(m, torch.where(mask_exact, kappa, ks.expand_as(kappa))), ret)
+
+    def _evaluate(self, prediction: Tensor, target: Tensor) -> Tensor:
+        assert prediction.dim() == 2 and target.dim() == 2 and prediction.size() == target.size()
+        m = target.size()[1]
+        k = torch.norm(prediction, dim=1)
+        return -self.log_cmk(m, k) - torch.sum(prediction * target, dim=1)
+
+
+class VonMisesFisher2DLoss(VonMisesFisherLoss):
+    """``loss_functions.py:359-397``: prediction [N, 2] = (angle, kappa), target [N, 1] = angle."""
+
+    def _forward(self, prediction: Tensor, target: Tensor) -> Tensor:
+        assert prediction.dim() == 2 and prediction.size()[1] == 2 and target.dim() == 2
+        t = torch.stack([torch.cos(target[:, 0]), torch.sin(target[:, 0])], dim=1)
+        p = prediction[:, 1].unsqueeze(1) * torch.stack([torch.cos(prediction[:, 0]), torch.sin(prediction[:, 0])], dim=1)
+        return self._evaluate(p, t)
+
+
+class VonMisesFisher3DLoss(VonMisesFisherLoss):
+    """``loss_functions.py:424-447``: prediction [N, 4] = (unit direction, kappa), target [N, 3]."""
+
+    def _forward(self, prediction: Tensor, target: Tensor) -> Tensor:
+        target = target.reshape(-1, 3)
+        assert prediction.dim() == 2 and prediction.size()[1] == 4 and prediction.size()[0] == target.size()[0]
+        return self._evaluate(prediction[:, 3].unsqueeze(1) * prediction[:, [0, 1, 2]], target)
+
+
 class Task(Model):
     """``models/task/task.py:22-222`` (transform handling reduced to what the path uses)."""
 
@@ -142,8 +208,14 @@ class StandardLearnedTask(Task):
 
 
 class IdentityTask(StandardLearnedTask):
+    """``task.py:340-386``: the affine head's output is the prediction; default prediction labels
+    ``target_{i}_pred``."""
+
     def __init__(self, nb_outputs: int, target_labels: Union[List[str], Any], *args: Any, **kwargs: Any):
         self.nb_inputs = nb_outputs  # type: ignore[misc]
+        labels = target_labels if isinstance(target_labels, list) else [target_labels]
+        self.default_target_labels = labels
+        self.default_prediction_labels = [f"target_{i}_pred" for i in range(len(labels))]
         super().__init__(*args, target_labels=target_labels, **kwargs)
 
     def _forward(self, x: Tensor) -> Tensor:
@@ -159,6 +231,64 @@ class EnergyReconstruction(StandardLearnedTask):
 
     def _forward(self, x: Tensor) -> Tensor:
         return torch.nn.functional.softplus(x, beta=0.05) + eps_like(x)
+
+
+class BinaryClassificationTask(StandardLearnedTask):
+    """``task/classification.py:18-28``: one logit -> probability."""
+
+    nb_inputs = 1
+    default_target_labels = ["target"]
+    default_prediction_labels = ["target_pred"]
+
+    def _forward(self, x: Tensor) -> Tensor:
+        return torch.sigmoid(x)
+
+
+class BinaryClassificationTaskLogits(StandardLearnedTask):
+    """``task/classification.py:31-40``."""
+
+    nb_inputs = 1
+    default_target_labels = ["target"]
+    default_prediction_labels = ["target_pred"]
+
+    def _forward(self, x: Tensor) -> Tensor:
+        return x
+
+
+class ZenithReconstruction(StandardLearnedTask):
+    """``task/reconstruction.py:73-83``."""
+
+    default_target_labels = ["zenith"]
+    default_prediction_labels = ["zenith_pred"]
+    nb_inputs = 1
+
+    def _forward(self, x: Tensor) -> Tensor:
+        return torch.sigmoid(x[:, :1]) * np.pi
+
+
+class ZenithReconstructionWithKappa(ZenithReconstruction):
+    """``task/reconstruction.py:86-98``: zenith and kappa (1 / variance)."""
+
+    default_target_labels = ["zenith"]
+    default_prediction_labels = ["zenith_pred", "zenith_kappa"]
+    nb_inputs = 2
+
+    def _forward(self, x: Tensor) -> Tensor:
+        angle = super()._forward(x[:, :1]).squeeze(1)
+        kappa = torch.abs(x[:, 1]) + eps_like(x)
+        return torch.stack((angle, kappa), dim=1)
+
+
+class DirectionReconstructionWithKappa(StandardLearnedTask):
+    """``task/reconstruction.py:49-70``: unit direction and kappa of the 3D vMF distribution."""
+
+    default_target_labels = ["direction"]
+    default_prediction_labels = ["dir_x_pred", "dir_y_pred", "dir_z_pred", "direction_kappa"]
+    nb_inputs = 3
+
+    def _forward(self, x: Tensor) -> Tensor:
+        kappa = torch.linalg.vector_norm(x, dim=1) + eps_like(x)
+        return torch.stack((x[:, 0] / kappa, x[:, 1] / kappa, x[:, 2] / kappa, kappa), dim=1)
 
 
 # ------------------------------------------------------------------------------ LR schedule
@@ -281,6 +411,52 @@ class StandardModel(Model):
                 if log_every and step % log_every == 0:
                     history.append(float(loss.detach()))
         return history
+
+    def predict_as_dataframe(self, batches: Sequence[Any], prediction_columns: Optional[List[str]] = None, *,
+                             additional_attributes: Optional[List[str]] = None, device: str = "cuda"):
+        """``easy_model.py:321-433``: predictions (one column per prediction label) plus the requested batch
+        attributes as a ``pandas.DataFrame``.  Pulse-level predictions (more rows than events) repeat event-level
+        attributes once per pulse (``l.388-405``)."""
+        import pandas as pd
+        if prediction_columns is None:
+            prediction_columns = self.prediction_labels
+        additional_attributes = list(additional_attributes or [])
+        batches = list(batches)
+        predictions = torch.cat(self.predict(batches, device=device), dim=1).detach().cpu().numpy()
+        assert len(prediction_columns) == predictions.shape[1], (
+            f"Number of provided column names ({len(prediction_columns)}) and number of output columns "
+            f"({predictions.shape[1]}) don't match.")
+        n_events = sum(int(b.n_pulses.shape[0]) for b in batches)
+        pulse_level = len(predictions) > n_events
+        attributes: Dict[str, List[np.ndarray]] = {a: [] for a in additional_attributes}
+        for b in batches:
+            for attr in attributes:
+                val = b[attr]
+                if isinstance(val, Tensor):
+                    val = val.detach().cpu().numpy()
+                if pulse_level and len(val) < int(b.n_pulses.sum()):
+                    val = np.repeat(val, b.n_pulses.detach().cpu().numpy())
+                attributes[attr].append(val)
+        data = np.concatenate([predictions] + [np.concatenate(attributes[a]).reshape(len(predictions), -1)
+                                               for a in additional_attributes], axis=1)
+        return pd.DataFrame(data, columns=list(prediction_columns) + additional_attributes)
+
+    # Lightning ``ModelCheckpoint`` layout (``easy_model.py:143-170``: ``.ckpt`` files hold ``state_dict`` next to the
+    # trainer counters); written with tensors only, read with ``weights_only=True``
+    def save_checkpoint(self, path: str, optimizer: Optional[torch.optim.Optimizer] = None, epoch: int = 0,
+                        global_step: int = 0) -> None:
+        ckpt: Dict[str, Any] = {"epoch": epoch, "global_step": global_step, "pytorch-lightning_version": "2.0.0",
+                                "state_dict": self.state_dict(), "loops": None, "callbacks": {},
+                                "optimizer_states": [optimizer.state_dict()] if optimizer is not None else [],
+                                "lr_schedulers": []}
+        torch.save(ckpt, path)
+
+    def load_checkpoint(self, path: str, strict: bool = True) -> Dict[str, Any]:
+        """Load the ``state_dict`` of a Lightning ``.ckpt`` (legacy ``_gnn.`` keys renamed, ``model.py:72-74``);
+        returns the rest of the checkpoint (epoch, global_step, optimizer_states ...)."""
+        ckpt = torch.load(path, weights_only=True, map_location="cpu")
+        self.load_state_dict(ckpt["state_dict"], strict=strict)
+        return {k: v for k, v in ckpt.items() if k != "state_dict"}
 
     @torch.no_grad()
     def predict(self, batches: Sequence[Any], device: str = "cuda") -> List[Tensor]:

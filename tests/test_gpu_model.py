@@ -213,3 +213,49 @@ def test_graphed_step_equals_eager_step():
     assert losses1 == losses2
     for p1, p2 in zip(m1.parameters(), m2.parameters()):
         assert torch.equal(p1, p2)
+
+
+def test_queso_style_model_and_predict_as_dataframe(oracle):
+    """The shape of the reference's shipped IceCube-Upgrade models (``models/pretrained/icecube/upgrade/QUESO``):
+    14 input features, pools [min, max, mean], default DynEdge sizes; event-level and pulse-level
+    (``global_pooling_schemes=None``) heads through ``predict_as_dataframe`` (``easy_model.py:321-433``)."""
+    import graphnet_amd as g
+    from graphnet_amd import standard_model as sm
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    def batch(seed, n):
+        b = synthetic_icecube86_batch(n, seed=seed)
+        gen = torch.Generator().manual_seed(seed)
+        b.x = torch.cat([b.x, torch.randn(b.x.shape[0], 7, generator=gen) * 0.5], dim=1)   # 14 features
+        b.event_no = torch.arange(n) + 100 * seed
+        return b
+    torch.manual_seed(4)
+    ref = oracle.DynEdgeOracle(14, global_pooling_schemes=["min", "max", "mean"])
+    m = g.StandardModel(graph_definition=g.KNNGraph(g.IceCubeUpgrade()),
+                        backbone=g.DynEdge(14, global_pooling_schemes=["min", "max", "mean"]),
+                        tasks=[sm.IdentityTask(nb_outputs=1, target_labels="energy", hidden_size=128,
+                                               loss_function=g.LogCoshLoss(), transform_target=torch.log10,
+                                               transform_inference=lambda x: torch.pow(10, x))])
+    m.backbone.load_state_dict(ref.state_dict())
+    m.to(DEV)
+    m.backbone.set_backend(dtype="fp32")
+    bs = [batch(1, 5), batch(2, 4)]
+    df = m.predict_as_dataframe(bs, additional_attributes=["event_no"])
+    assert list(df.columns) == ["target_0_pred", "event_no"] and len(df) == 9
+    assert list(df["event_no"]) == [100, 101, 102, 103, 104, 200, 201, 202, 203]
+    b0 = batch(1, 5)
+    ei = oracle.knn_graph(b0.x, 8, b0.batch, [0, 1, 2])
+    lat = ref(b0.x, ei, b0.batch, b0.n_pulses)
+    want = torch.pow(10, m._tasks[0]._affine.cpu()(lat)).detach()[:, 0]
+    got = torch.tensor(df["target_0_pred"].values[:5], dtype=torch.float32)
+    assert rel_err(got, want) < 1e-4
+    # pulse-level head: one row per pulse, event attributes repeated per pulse
+    torch.manual_seed(5)
+    mp = g.StandardModel(graph_definition=g.KNNGraph(g.IceCubeUpgrade()),
+                         backbone=g.DynEdge(14, global_pooling_schemes=None),
+                         tasks=[sm.BinaryClassificationTask(hidden_size=128, loss_function=sm.BinaryCrossEntropyLoss(),
+                                                            target_labels="truth_flag")]).to(DEV)
+    dfp = mp.predict_as_dataframe(bs, additional_attributes=["event_no"])
+    n0 = int(bs[0].n_pulses.sum())
+    assert len(dfp) == sum(int(b.n_pulses.sum()) for b in bs) and list(dfp.columns) == ["target_pred", "event_no"]
+    assert bool(((dfp["target_pred"] > 0) & (dfp["target_pred"] < 1)).all())
+    assert list(dfp["event_no"][:int(bs[0].n_pulses[0])]) == [100.0] * int(bs[0].n_pulses[0]) and dfp["event_no"][n0] == 200

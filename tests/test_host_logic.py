@@ -161,3 +161,169 @@ def test_device_ops_fail_loudly_on_cpu_tensors():
     b = synthetic_icecube86_batch(2, seed=1)
     with pytest.raises(RuntimeError):
         g.DynEdge(7)(b)
+
+
+# ------------------------------------------------------------------------------ config / checkpoint / task surface (§8 f4)
+_REFERENCE_STYLE_CONFIG = """
+arguments:
+  backbone:
+    ModelConfig:
+      arguments: {add_global_variables_after_pooling: false, dynedge_layer_sizes: null,
+        features_subset: null, global_pooling_schemes: [min, max, mean], nb_inputs: 14, nb_neighbours: 8,
+        post_processing_layer_sizes: null, readout_layer_sizes: null}
+      class_name: DynEdge
+  graph_definition:
+    ModelConfig:
+      arguments:
+        columns: [0, 1, 2]
+        detector:
+          ModelConfig:
+            arguments: {}
+            class_name: IceCubeUpgrade
+        dtype: torch.float32
+        nb_nearest_neighbours: 8
+        node_definition:
+          ModelConfig:
+            arguments: {}
+            class_name: NodesAsPulses
+        input_feature_names: [dom_x, dom_y, dom_z, dom_time, charge, rde, pmt_area, string, pmt_number, dom_number,
+          pmt_dir_x, pmt_dir_y, pmt_dir_z, dom_type]
+      class_name: KNNGraph
+  optimizer_class: '!class torch.optim.adam Adam'
+  optimizer_kwargs: null
+  scheduler_class: null
+  scheduler_config: null
+  scheduler_kwargs: null
+  tasks:
+  - ModelConfig:
+      arguments:
+        nb_outputs: 1
+        hidden_size: 128
+        loss_function:
+          ModelConfig:
+            arguments: {}
+            class_name: LogCoshLoss
+        loss_weight: null
+        prediction_labels: null
+        target_labels: energy
+        transform_inference: '!lambda x: torch.pow(10,x)'
+        transform_prediction_and_target: null
+        transform_support: null
+        transform_target: '!lambda x: torch.log10(x)'
+      class_name: IdentityTask
+class_name: StandardModel
+"""
+
+
+def test_reference_style_model_config_loads_and_round_trips(tmp_path):
+    """The layout of the reference's shipped configs (``models/pretrained/icecube/upgrade/QUESO/*/*_config.yml``:
+    nested ``ModelConfig:`` keys, ``!class`` / ``!lambda`` strings, ``dtype: torch.float32``).  Nothing in a config is
+    ever evaluated: an unknown lambda is refused."""
+    import torch
+    import graphnet_amd as g
+    from graphnet_amd.model import ModelConfig
+    path = tmp_path / "cfg.yml"
+    path.write_text(_REFERENCE_STYLE_CONFIG)
+    m = g.Model.from_config(str(path))
+    assert type(m).__name__ == "StandardModel" and type(m.backbone).__name__ == "DynEdge"
+    assert m.backbone.nb_inputs == 14 and m.backbone._global_pooling_schemes == ["min", "max", "mean"]
+    assert m._optimizer_class is torch.optim.Adam
+    assert m.prediction_labels == ["target_0_pred"] and m.target_labels == ["energy"]
+    task = m._tasks[0]
+    x = torch.tensor([10.0, 1000.0])
+    assert torch.allclose(task._transform_target(x), torch.log10(x))
+    assert torch.allclose(task._transform_prediction_inference(torch.log10(x)), x)
+    text = m.config.dump()
+    assert "!lambda x: torch.log10(x)" in text and "!class torch.optim.adam Adam" in text and "ModelConfig:" in text
+    m2 = ModelConfig.load(_write(tmp_path / "again.yml", text)).construct()
+    assert m2.config.dump() == text
+    assert list(m2.state_dict()) == list(m.state_dict())
+    bad = _REFERENCE_STYLE_CONFIG.replace("x: torch.log10(x)", "x: __import__(\"os\").system(\"true\")")
+    with pytest.raises(ValueError, match="never evaluates"):
+        ModelConfig.load(_write(tmp_path / "bad.yml", bad)).construct()
+
+
+def _write(path, text):
+    path.write_text(text)
+    return str(path)
+
+
+def test_lightning_layout_checkpoint_round_trip(tmp_path):
+    """``save_checkpoint`` writes the Lightning ``.ckpt`` layout (``state_dict`` + trainer counters), readable with
+    ``weights_only=True``; legacy ``_gnn.`` keys are renamed on load (``models/model.py:72-74``)."""
+    import torch
+    import graphnet_amd as g
+    def make():
+        return g.StandardModel(graph_definition=g.KNNGraph(g.IceCube86()), backbone=g.DynEdge(7, dynedge_layer_sizes=[(16, 32)]),
+                               tasks=[g.EnergyReconstruction(hidden_size=128, loss_function=g.LogCoshLoss())])
+    torch.manual_seed(0)
+    a = make()
+    opt = torch.optim.Adam(a.parameters())
+    a.save_checkpoint(str(tmp_path / "m.ckpt"), optimizer=opt, epoch=3, global_step=77)
+    raw = torch.load(str(tmp_path / "m.ckpt"), weights_only=True)
+    assert {"state_dict", "epoch", "global_step", "optimizer_states", "lr_schedulers", "pytorch-lightning_version"} <= set(raw)
+    torch.manual_seed(1)
+    b = make()
+    rest = b.load_checkpoint(str(tmp_path / "m.ckpt"))
+    assert rest["epoch"] == 3 and rest["global_step"] == 77
+    assert all(torch.equal(p, q) for p, q in zip(a.state_dict().values(), b.state_dict().values()))
+    legacy = {k.replace("backbone.", "_gnn."): v for k, v in a.state_dict().items()}
+    torch.save({"state_dict": legacy}, str(tmp_path / "old.ckpt"))
+    torch.manual_seed(2)
+    c = make()
+    c.load_checkpoint(str(tmp_path / "old.ckpt"))
+    assert all(torch.equal(p, q) for p, q in zip(a.state_dict().values(), c.state_dict().values()))
+
+
+@pytest.mark.parametrize("m", [2, 3])
+def test_von_mises_fisher_log_cmk_known_answers(m):
+    """Pins: the closed form the reference's own test uses for m = 3 (``tests/training/test_loss_functions.py:66-96``),
+    the Bessel-function definition via scipy for both m, gradients -I_{m/2}(k) / I_{m/2-1}(k), the inequality and
+    tolerances of ``:99-143`` for the approximation, and continuity of ``log_cmk`` at the switch."""
+    import scipy.special
+    import torch
+    from graphnet_amd.standard_model import VonMisesFisherLoss as V
+    k = torch.tensor([0.0001, 0.001, 0.01, 0.1, 1.0, 3.0, 10.0, 30.0, 100.0], dtype=torch.float64, requires_grad=True)
+    got = V.log_cmk_exact(m, k)
+    kn = k.detach().numpy()
+    want = (m / 2.0 - 1) * np.log(kn) - np.log(scipy.special.iv(m / 2.0 - 1, kn)) - (m / 2) * np.log(2 * np.pi)
+    assert np.allclose(got.detach().numpy(), want, rtol=1e-10, atol=1e-12)
+    if m == 3:
+        ref = torch.log(k) - k - torch.log(2 * np.pi * (1 - torch.exp(-2 * k)))
+        assert torch.allclose(got, ref)
+    (grad,) = torch.autograd.grad(got.sum(), k)
+    assert np.allclose(grad.numpy(), -scipy.special.iv(m / 2.0, kn) / scipy.special.iv(m / 2.0 - 1, kn), rtol=1e-7)
+    approx = V.log_cmk_approx(m, k)
+    shifted = approx + (got[0] - approx[0]) - torch.finfo(torch.float64).eps
+    assert torch.all(got >= shifted)
+    assert torch.allclose(shifted, got, rtol=1e0, atol=1e-1)
+    big = torch.tensor([99.999999, 100.0, 100.000001, 500.0, 5000.0], dtype=torch.float64)
+    vals = V.log_cmk(m, big)
+    assert torch.isfinite(vals).all() and abs(float(vals[0] - vals[2])) < 1e-5
+
+
+def test_task_heads_and_losses():
+    """Transforms of the heads the reference's configs name (``task/reconstruction.py:49-98``,
+    ``task/classification.py:18-40``) and the 2D / 3D vMF losses on a hand-checkable case."""
+    import torch
+    import graphnet_amd as g
+    from graphnet_amd import standard_model as sm
+    torch.manual_seed(0)
+    h = torch.randn(5, 16)
+    z = sm.ZenithReconstructionWithKappa(hidden_size=16, loss_function=sm.VonMisesFisher2DLoss())
+    p = z(h)
+    assert p.shape == (5, 2) and bool(((p[:, 0] > 0) & (p[:, 0] < np.pi)).all()) and bool((p[:, 1] > 0).all())
+    d = sm.DirectionReconstructionWithKappa(hidden_size=16, loss_function=sm.VonMisesFisher3DLoss())
+    q = d(h)
+    assert torch.allclose(q[:, :3].norm(dim=1), torch.ones(5), atol=1e-5) and bool((q[:, 3] > 0).all())
+    b = sm.BinaryClassificationTask(hidden_size=16, loss_function=sm.BinaryCrossEntropyLoss())
+    pr = b(h)
+    assert bool(((pr > 0) & (pr < 1)).all())
+    t = torch.tensor([[1.0], [0.0], [1.0], [0.0], [1.0]])
+    loss = b.compute_loss(pr, {"target": t[:, 0]})
+    assert torch.allclose(loss, torch.nn.functional.binary_cross_entropy(pr, t))
+    # aligned prediction has a lower vMF loss than an anti-aligned one, and the loss is differentiable in kappa
+    ang = torch.tensor([[0.3], [1.0]])
+    good = sm.VonMisesFisher2DLoss()(torch.tensor([[0.3, 5.0], [1.0, 5.0]]), ang)
+    bad = sm.VonMisesFisher2DLoss()(torch.tensor([[0.3 + np.pi, 5.0], [1.0 + np.pi, 5.0]]), ang)
+    assert float(good) < float(bad) and abs(float(bad - good) - 10.0) < 1e-4      # 2 * kappa
