@@ -598,3 +598,40 @@ def test_persistent_kernels_match_generic_kernels(oracle):
             close(res["v2"][k], res["v1"][k], k)
         nrows = N * g.S + int(g.ovf_cnt.item())
         close(res["v2"]["dpre"][:nrows], res["v1"]["dpre"][:nrows], "dpre")
+
+
+@pytest.mark.parametrize("name,mode,tol", MODES)
+def test_dynedge_as_embedded_in_deepice(oracle, name, mode, tol):
+    """The DynEdge that ``DeepIce(include_dynedge=True)`` embeds (``models/gnn/icemix.py:100-118``): 9 neighbours in
+    the re-clustering, GELU, LayerNorm, no pooling, no read-out (node-level features), fed with the loader's
+    6-neighbour graph over (x, y, z, t)."""
+    import graphnet_amd as g
+    b = _batch(6, seed=23)
+    kw = dict(nb_neighbours=9, post_processing_layer_sizes=[336, 96], dynedge_layer_sizes=[(128, 256), (336, 256)],
+              global_pooling_schemes=None, activation_layer="gelu", add_norm_layer=True, skip_readout=True)
+    torch.manual_seed(9)
+    ref = oracle.DynEdgeOracle(7, **kw)
+    m = g.DynEdge(7, **kw)
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).set_backend(dtype=name)
+    ei0 = oracle.knn_graph(b.x, 6, b.batch, [0, 1, 2, 3])
+    b.edge_index = ei0
+    y, trace = m(b.to(DEV), return_trace=True)
+    assert y.shape == (b.x.shape[0], 96)
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
+    (y * w.to(DEV)).sum().backward()
+    bc = b.to("cpu")
+    forced = [t.edge_index().cpu() for t in trace["graphs"]]
+    assert torch.equal(forced[0], ei0)
+    coords = trace["knn_coords"][0].cpu()                                  # layer-2 graph: 9 neighbours, bit-exact
+    assert torch.equal(forced[1], oracle.knn_graph(coords, 9, bc.batch, [0, 1, 2]))
+    yo = ref(bc.x, ei0, bc.batch, bc.n_pulses, forced_edges=forced)
+    (yo * w).sum().backward()
+    assert rel_err(y, yo.detach()) < tol
+    for (kn, p), (_, po) in zip(m.named_parameters(), ref.named_parameters()):
+        if po.grad is None:
+            continue
+        if mode == 0:
+            assert rel_err(p.grad, po.grad) < 2e-3, f"{name}: grad {kn}"
+        else:
+            assert norm_err(p.grad, po.grad) < 5e-2, f"{name}: grad {kn}"
