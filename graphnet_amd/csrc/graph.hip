@@ -26,7 +26,7 @@ struct KnnCols { int c[KNN_DMAX]; };
 // wave only ever scans candidates of ITS OWN event (a tile spanning events would scan their union).
 // tile_ptr[e] = sum_{e'<e} ceil(n_e'/64) is built once per batch by knn_plan_kernel; a workgroup (one
 // wave) finds its event by binary search over tile_ptr (wave-uniform scalar loads).
-constexpr int KNN_BIG = 1024;  // events above this many pulses: candidates split over 8 waves per query tile
+constexpr int KNN_BIG = 256;   // events above this many pulses: candidates split over 8 waves per query tile
 __global__ __launch_bounds__(256) void knn_plan_kernel(const int* __restrict__ ptr, int B, int* __restrict__ tile_ptr) {
     __shared__ int lds[256 / 64];
     int carry = 0;

@@ -2,8 +2,9 @@
 """profiles/r01_traffic.json from two rocprofv3 --pmc passes over bench.py (FETCH_SIZE, WRITE_SIZE).
 HBM bytes per launch of the dominant kernel of every op group, corrected as MI355X_MICROARCH.md prescribes
 (FETCH_SIZE / WRITE_SIZE are in KB; gfx950 counts wide coalesced reads at half size -> FETCH doubled).
-usage: traffic_from_pmc.py fetch.db write.db out.json"""
+usage: traffic_from_pmc.py fetch.db write.db out.json [events_per_gpu]"""
 import json, sqlite3, sys
+EVENTS = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 GROUPS = {  # op group of bench.py -> substring of its dominant kernel
     "edgeconv_fwd": "edge_fwd_v2_kernelILi22", "edgeconv_bwd": "edge_bwd_v2_kernelILi11",
     "edgeconv_dw2": "edge_dw2_v2_kernelILi11", "edgeconv_dq_gather": "dq_gather_kernel",
@@ -27,7 +28,8 @@ for grp, sub in GROUPS.items():
         continue
     out[grp] = {"kernel": sub, "FETCH_SIZE_KB": f[1][0], "WRITE_SIZE_KB": w[1][0], "launches": f[1][1],
                 "bytes_per_launch": (2.0 * f[1][0] + w[1][0]) * 1024.0,
+                "events_per_gpu": EVENTS,
                 "note": "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads), WRITE_SIZE as is; "
-                        "separate --pmc passes over bench.py, B=1024"}
+                        f"separate --pmc passes over bench.py, B={EVENTS}"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: round(v["bytes_per_launch"] / 1e6, 1) for k, v in out.items()}), "MB per launch")
