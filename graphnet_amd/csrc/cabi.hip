@@ -202,16 +202,20 @@ int gn_edge_gather_pre(const float* PQ, int32_t H1p, const int32_t* ic, const in
 }
 int gn_rownorm_act_fwd(const float* z, int64_t ldz, int32_t C, const int32_t* valid, const float* gamma, const float* beta,
                        float eps, int32_t act, float* a, int64_t lda, int32_t Cpad, float* stats, int64_t rows,
-                       void* stream) {
-    hipError_t r = gn::launch_rownorm_act_fwd(z, ldz, C, valid, gamma, beta, eps, act, a, lda, Cpad, stats, rows, S(stream));
+                       void* a_bf16, int64_t lda_bf16, void* stream) {
+    if (!a && !a_bf16) return bad("gn_rownorm_act_fwd", "a and / or a_bf16");
+    hipError_t r = gn::launch_rownorm_act_fwd(z, ldz, C, valid, gamma, beta, eps, act, a, lda, Cpad, stats, rows, a_bf16,
+                                              lda_bf16, S(stream));
     if (r == hipErrorInvalidValue) return bad("gn_rownorm_act_fwd", "need 1 <= C <= Cpad <= 512, act in 0..3, gamma and beta together");
     return fail(r, "gn_rownorm_act_fwd");
 }
 int gn_rownorm_act_bwd(const float* g, int64_t ldg, const int32_t* gidx, const float* z, int64_t ldz, int32_t C,
                        const int32_t* valid, const float* gamma, const float* beta, const float* stats, int32_t act,
-                       float* dz, int64_t lddz, int32_t Cpad, float* t_dy, float* t_dyx, int64_t rows, void* stream) {
+                       float* dz, int64_t lddz, int32_t Cpad, float* t_dy, float* t_dyx, int64_t rows, void* dz_bf16,
+                       int64_t lddz_bf16, void* stream) {
+    if (!dz && !dz_bf16) return bad("gn_rownorm_act_bwd", "dz and / or dz_bf16");
     hipError_t r = gn::launch_rownorm_act_bwd(g, ldg, gidx, z, ldz, C, valid, gamma, beta, stats, act, dz, lddz, Cpad, t_dy,
-                                              t_dyx, rows, S(stream));
+                                              t_dyx, rows, dz_bf16, lddz_bf16, S(stream));
     if (r == hipErrorInvalidValue) return bad("gn_rownorm_act_bwd", "need 1 <= C <= Cpad <= 512, act in 0..3; LayerNorm needs beta, stats, t_dy, t_dyx");
     return fail(r, "gn_rownorm_act_bwd");
 }

@@ -84,7 +84,8 @@ template <bool NORM, int ACT>
 __global__ __launch_bounds__(256) void rownorm_act_fwd_kernel(
     const float* __restrict__ z, long long ldz, int C, const int* __restrict__ valid,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    float* __restrict__ a, long long lda, int Cpad, float* __restrict__ stats, long long rows)
+    float* __restrict__ a, long long lda, int Cpad, float* __restrict__ stats, long long rows,
+    __bf16* __restrict__ a16, long long lda16)          // a and / or a16 (bf16 copy for the GEMMs that consume it)
 {
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(256) void rownorm_act_fwd_kernel(
                 if constexpr (NORM) y = (y - mean) * rstd * gamma[c] + beta[c];
                 o = act_fwd<ACT>(y);
             }
-            a[r * lda + c] = o;
+            if (a) a[r * lda + c] = o;
+            if (a16) a16[r * lda16 + c] = (__bf16)o;
         }
     }
 }
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(256) void rownorm_act_bwd_kernel(
     const float* __restrict__ g, long long ldg, const int* __restrict__ gidx,
     const float* __restrict__ z, long long ldz, int C, const int* __restrict__ valid,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats,
-    float* __restrict__ dz, long long lddz, int Cpad, float* __restrict__ t_dy, float* __restrict__ t_dyx, long long rows)
+    float* __restrict__ dz, long long lddz, int Cpad, float* __restrict__ t_dy, float* __restrict__ t_dyx, long long rows,
+    __bf16* __restrict__ dz16, long long lddz16)
 {
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(256) void rownorm_act_bwd_kernel(
                 if constexpr (NORM) o = rstd * (dy[k] * gamma[c] - s1 - xh[k] * s2);
                 else o = dy[k];
             }
-            dz[r * lddz + c] = o;
+            if (dz) dz[r * lddz + c] = o;
+            if (dz16) dz16[r * lddz16 + c] = (__bf16)o;
         }
         if constexpr (NORM) {
             if (c < C) {
@@ -292,13 +296,13 @@ hipError_t launch_edge_gather_pre(const float* PQ, int H1p, const int* ic, const
 }
 hipError_t launch_rownorm_act_fwd(const float* z, long long ldz, int C, const int* valid, const float* gamma,
                                   const float* beta, float eps, int act, float* a, long long lda, int Cpad, float* stats,
-                                  long long rows, hipStream_t st) {
+                                  long long rows, void* a16, long long lda16, hipStream_t st) {
     if (rows == 0) return hipSuccess;
     if (C < 1 || Cpad < C || Cpad > RN_MAXC || act < 0 || act > 3 || ((gamma != nullptr) != (beta != nullptr)))
         return hipErrorInvalidValue;
     const dim3 grid(gblocks(rows, 4)), block(256);
     const bool norm = gamma != nullptr;
-#define GN_RN_FWD(NRM, ACT) hipLaunchKernelGGL((rownorm_act_fwd_kernel<NRM, ACT>), grid, block, 0, st, z, ldz, C, valid, gamma, beta, eps, a, lda, Cpad, stats, rows)
+#define GN_RN_FWD(NRM, ACT) hipLaunchKernelGGL((rownorm_act_fwd_kernel<NRM, ACT>), grid, block, 0, st, z, ldz, C, valid, gamma, beta, eps, a, lda, Cpad, stats, rows, (__bf16*)a16, lda16)
     if (norm) { if (act == 0) GN_RN_FWD(true, 0); else if (act == 1) GN_RN_FWD(true, 1); else if (act == 2) GN_RN_FWD(true, 2); else GN_RN_FWD(true, 3); }
     else { if (act == 0) GN_RN_FWD(false, 0); else if (act == 1) GN_RN_FWD(false, 1); else if (act == 2) GN_RN_FWD(false, 2); else GN_RN_FWD(false, 3); }
 #undef GN_RN_FWD
@@ -307,13 +311,13 @@ hipError_t launch_rownorm_act_fwd(const float* z, long long ldz, int C, const in
 hipError_t launch_rownorm_act_bwd(const float* g, long long ldg, const int* gidx, const float* z, long long ldz, int C,
                                   const int* valid, const float* gamma, const float* beta, const float* stats, int act,
                                   float* dz, long long lddz, int Cpad, float* t_dy, float* t_dyx, long long rows,
-                                  hipStream_t st) {
+                                  void* dz16, long long lddz16, hipStream_t st) {
     if (rows == 0) return hipSuccess;
     const bool norm = gamma != nullptr;
     if (C < 1 || Cpad < C || Cpad > RN_MAXC || act < 0 || act > 3 || (norm && (!beta || !stats || !t_dy || !t_dyx)))
         return hipErrorInvalidValue;
     const dim3 grid(gblocks(rows, 4)), block(256);
-#define GN_RN_BWD(NRM, ACT) hipLaunchKernelGGL((rownorm_act_bwd_kernel<NRM, ACT>), grid, block, 0, st, g, ldg, gidx, z, ldz, C, valid, gamma, beta, stats, dz, lddz, Cpad, t_dy, t_dyx, rows)
+#define GN_RN_BWD(NRM, ACT) hipLaunchKernelGGL((rownorm_act_bwd_kernel<NRM, ACT>), grid, block, 0, st, g, ldg, gidx, z, ldz, C, valid, gamma, beta, stats, dz, lddz, Cpad, t_dy, t_dyx, rows, (__bf16*)dz16, lddz16)
     if (norm) { if (act == 0) GN_RN_BWD(true, 0); else if (act == 1) GN_RN_BWD(true, 1); else if (act == 2) GN_RN_BWD(true, 2); else GN_RN_BWD(true, 3); }
     else { if (act == 0) GN_RN_BWD(false, 0); else if (act == 1) GN_RN_BWD(false, 1); else if (act == 2) GN_RN_BWD(false, 2); else GN_RN_BWD(false, 3); }
 #undef GN_RN_BWD

@@ -469,27 +469,32 @@ def edge_gather_pre(PQ: Tensor, H1p: int, ic: Tensor, jc: Tensor) -> Tensor:
 
 
 def rownorm_act_fwd(z: Tensor, C: int, act: str, gamma: Optional[Tensor] = None, beta: Optional[Tensor] = None,
-                    valid: Optional[Tensor] = None, cpad: Optional[int] = None, eps: float = 1e-5):
-    """``act(LayerNorm(z[:, :C]))`` (LayerNorm only with gamma/beta) -> (a [R, cpad] fp32, stats [R, 2] | None)."""
+                    valid: Optional[Tensor] = None, cpad: Optional[int] = None, eps: float = 1e-5, lowp: str = "no"):
+    """``act(LayerNorm(z[:, :C]))`` (LayerNorm only with gamma/beta) -> (a [R, cpad] fp32, stats [R, 2] | None).
+    ``lowp``: "no" (fp32 result), "only" (bf16 result instead: operands of the MFMA GEMMs that are not needed in
+    fp32) or "both" -> ((a fp32, a bf16), stats)."""
     _need(z, torch.float32, "z")
     R = int(z.shape[0])
     cpad = C if cpad is None else cpad
-    a = torch.empty((R, cpad), dtype=torch.float32, device=z.device)
+    a = torch.empty((R, cpad), dtype=torch.float32, device=z.device) if lowp != "only" else None
+    a16 = torch.empty((R, cpad), dtype=torch.bfloat16, device=z.device) if lowp != "no" else None
     stats = torch.empty((R, 2), dtype=torch.float32, device=z.device) if gamma is not None else None
     with _timed("generic_rows"):
         _lib.check(_lib.lib().gn_rownorm_act_fwd(_p(z), _rows(z, "z"), C, _p(valid), _p(gamma), _p(beta), float(eps),
-                                                 ACT_CODES[act], _p(a), cpad, cpad, _p(stats), R, _st()))
-    return a, stats
+                                                 ACT_CODES[act], _p(a), cpad, cpad, _p(stats), R, _p(a16), cpad, _st()))
+    return (a if lowp == "no" else a16 if lowp == "only" else (a, a16)), stats
 
 
 def rownorm_act_bwd(g: Tensor, z: Tensor, C: int, act: str, gamma: Optional[Tensor] = None, beta: Optional[Tensor] = None,
                     stats: Optional[Tensor] = None, valid: Optional[Tensor] = None, gidx: Optional[Tensor] = None,
-                    cpad: Optional[int] = None):
-    """Backward of :func:`rownorm_act_fwd` -> (dz [R, cpad], dgamma | None, dbeta | None)."""
+                    cpad: Optional[int] = None, lowp: str = "no"):
+    """Backward of :func:`rownorm_act_fwd` -> (dz [R, cpad], dgamma | None, dbeta | None); ``lowp`` as there
+    ("only": dz is bf16, "both": dz is the pair (fp32, bf16))."""
     _need(g, torch.float32, "g"); _need(z, torch.float32, "z")
     R = int(z.shape[0])
     cpad = C if cpad is None else cpad
-    dz = torch.empty((R, cpad), dtype=torch.float32, device=z.device)
+    dz = torch.empty((R, cpad), dtype=torch.float32, device=z.device) if lowp != "only" else None
+    dz16 = torch.empty((R, cpad), dtype=torch.bfloat16, device=z.device) if lowp != "no" else None
     t1 = t2 = None
     if gamma is not None:
         if C % 4:
@@ -499,10 +504,11 @@ def rownorm_act_bwd(g: Tensor, z: Tensor, C: int, act: str, gamma: Optional[Tens
     with _timed("generic_rows"):
         _lib.check(_lib.lib().gn_rownorm_act_bwd(_p(g), _rows(g, "g"), _p(gidx), _p(z), _rows(z, "z"), C, _p(valid),
                                                  _p(gamma), _p(beta), _p(stats), ACT_CODES[act], _p(dz), cpad, cpad,
-                                                 _p(t1), _p(t2), R, _st()))
+                                                 _p(t1), _p(t2), R, _p(dz16), cpad, _st()))
+    res = dz if lowp == "no" else dz16 if lowp == "only" else (dz, dz16)
     if gamma is None:
-        return dz, None, None
-    return dz, colsum(t2, C), colsum(t1, C)
+        return res, None, None
+    return res, colsum(t2, C), colsum(t1, C)
 
 
 def slot_sum(m: Tensor, C: int, g: NeighbourTable) -> Tensor:

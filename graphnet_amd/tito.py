@@ -59,16 +59,18 @@ class _DynTransFunction(torch.autograd.Function):
         PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), _wt(mode, Wpq, [Fin]), 2 * H1p, bias=bpq)
         ic, jc = ops.edge_rows(g)
         pre1 = ops.edge_gather_pre(PQ, H1p, ic, jc)
-        a1, _ = ops.rownorm_act_fwd(pre1, H1, "leaky_relu", valid=jc, cpad=H1p)
+        lp = mode == ops.MODE_BF16                  # GEMM-only operands are produced in bf16 (weights-stationary GEMM)
+        a1, _ = ops.rownorm_act_fwd(pre1, H1, "leaky_relu", valid=jc, cpad=H1p, lowp="only" if lp else "no")
         z2 = ops.linear_fwd(mode, [(a1, H1p)], _wt(mode, W2, [H1]), d, bias=b2.contiguous(), out_cols=dr)
         m, _ = ops.rownorm_act_fwd(z2, d, "leaky_relu", valid=jc, cpad=dr)
         conv, aux = ops.slot_reduce(m, d, g, "max")
         residual = Fin == d                                             # layers.py:183-186
         r = conv.add_(x) if residual else conv
-        y0, st0 = ops.rownorm_act_fwd(r, d, "identity", g0, be0)        # self.norm1
+        y0, st0 = ops.rownorm_act_fwd(r, d, "identity", g0, be0, lowp="both" if lp else "no")      # self.norm1
+        y0, y0g = y0 if lp else (y0, y0)            # fp32 for the residual stream, bf16 copy for the GEMMs
         # --- TransformerEncoderLayer, norm_first=False
         lowp = ops.attention_lowp(mode, d, H)       # bf16 qkv / attention output, matrix-core attention kernels
-        qkv = ops.linear_fwd(mode, _ksegs([(y0, d)]), _wt(mode, Win, [d]), 3 * d, bias=bin_.contiguous(), out_lowp=lowp)
+        qkv = ops.linear_fwd(mode, _ksegs([(y0g, d)]), _wt(mode, Win, [d]), 3 * d, bias=bin_.contiguous(), out_lowp=lowp)
         drop = cfg.get("drop")                      # None, or (thresh, [seed_attn, seed_1, seed_ffn, seed_2])
         th = drop[0] if drop else 0
         att, lse2 = ops.attention_fwd(qkv, H, ptr, plan, drop=(drop[1][0], th) if drop else None)
@@ -78,9 +80,10 @@ class _DynTransFunction(torch.autograd.Function):
         else:
             z1 = y0.clone()
             ops.linear_fwd(mode, _ksegs([(att, d)]), _wt(mode, Wout, [d]), d, bias=bout.contiguous(), out=z1, accum=True)
-        y1, st1 = ops.rownorm_act_fwd(z1, d, "identity", g1, be1)
+        y1, st1 = ops.rownorm_act_fwd(z1, d, "identity", g1, be1, lowp="both" if lp else "no")
+        y1, y1g = y1 if lp else (y1, y1)
         F = int(Wl1.shape[0])
-        h = ops.linear_fwd(mode, _ksegs([(y1, d)]), _wt(mode, Wl1, [d]), F, bias=bl1.contiguous(), relu=True,
+        h = ops.linear_fwd(mode, _ksegs([(y1g, d)]), _wt(mode, Wl1, [d]), F, bias=bl1.contiguous(), relu=True,
                            out_lowp=mode == ops.MODE_BF16)     # the 2048-wide hidden layer is stored in the operand type
         if drop:                                    # x + dropout2(linear2(dropout(relu(linear1(x)))))
             ops.dropout(h, drop[1][2], th, out=h)
@@ -91,7 +94,7 @@ class _DynTransFunction(torch.autograd.Function):
             ops.linear_fwd(mode, _ksegs([(h, F)]), _wt(mode, Wl2, [F]), d, bias=bl2.contiguous(), out=z3, accum=True)
         y2, st2 = ops.rownorm_act_fwd(z3, d, "identity", g2, be2)
         ctx.cfg, ctx.p = cfg, p
-        ctx.saved = (xin, Fin, pre1, a1, z2, aux, residual, r, st0, y0, qkv, att, lse2, z1, st1, y1, h, z3, st2)
+        ctx.saved = (xin, Fin, pre1, a1, z2, aux, residual, r, st0, y0g, qkv, att, lse2, z1, st1, y1g, h, z3, st2)
         return y2
 
     @staticmethod
@@ -110,8 +113,11 @@ class _DynTransFunction(torch.autograd.Function):
         # norm2, FFN
         drop = cfg.get("drop")
         th = drop[0] if drop else 0
-        dz3, grads[16], grads[17] = ops.rownorm_act_bwd(gy, z3, d, "identity", g2, be2, st2)
-        df = ops.dropout(dz3, drop[1][3], th) if drop else dz3
+        lp = mode == ops.MODE_BF16
+        dz3, grads[16], grads[17] = ops.rownorm_act_bwd(gy, z3, d, "identity", g2, be2, st2,
+                                                        lowp="both" if lp and not drop else "no")
+        dz3, dz3g = dz3 if lp and not drop else (dz3, dz3)      # fp32: residual gradient; bf16 copy: GEMM operand
+        df = ops.dropout(dz3, drop[1][3], th, out=torch.empty_like(dz3, dtype=ops.mode_dtype(mode))) if drop else dz3g
         grads[12], grads[13] = ops.linear_wgrad(mode, df, d, _ksegs([(h, F)]), with_bias=True)
         dh = ops.linear_fwd(mode, _ksegs([(df, d)]), _wt(mode, Wl2.t(), [d]), F, gate=h, out_lowp=h.dtype == torch.bfloat16)
         if drop:                # dropped hidden units are 0 in h (gate closed); the kept ones carry the 1/(1-p)
@@ -119,8 +125,10 @@ class _DynTransFunction(torch.autograd.Function):
         grads[10], grads[11] = ops.linear_wgrad(mode, dh, F, _ksegs([(y1, d)]), with_bias=True)
         ops.linear_fwd(mode, _ksegs([(dh, F)]), _wt(mode, Wl1.t(), [F]), d, out=dz3, accum=True)      # dy1
         # norm1, attention
-        dz1, grads[14], grads[15] = ops.rownorm_act_bwd(dz3, z1, d, "identity", g1, be1, st1)
-        dproj = ops.dropout(dz1, drop[1][1], th) if drop else dz1
+        dz1, grads[14], grads[15] = ops.rownorm_act_bwd(dz3, z1, d, "identity", g1, be1, st1,
+                                                        lowp="both" if lp and not drop else "no")
+        dz1, dz1g = dz1 if lp and not drop else (dz1, dz1)
+        dproj = ops.dropout(dz1, drop[1][1], th, out=torch.empty_like(dz1, dtype=ops.mode_dtype(mode))) if drop else dz1g
         grads[8], grads[9] = ops.linear_wgrad(mode, dproj, d, _ksegs([(att, d)]), with_bias=True)
         datt = ops.linear_fwd(mode, _ksegs([(dproj, d)]), _wt(mode, Wout.t(), [d]), d, out_lowp=qkv.dtype == torch.bfloat16)
         dqkv = ops.attention_bwd(qkv, H, ptr, plan, att, lse2, datt, drop=(drop[1][0], th) if drop else None)
@@ -131,7 +139,7 @@ class _DynTransFunction(torch.autograd.Function):
         # EdgeConvTito
         ic, jc = ops.edge_rows(g)
         grows = ops.slot_reduce_bwd(dres, d, g, "max", aux, cpad=dr)
-        dz2, _, _ = ops.rownorm_act_bwd(grows, z2, d, "leaky_relu", valid=jc, cpad=dr)
+        dz2, _, _ = ops.rownorm_act_bwd(grows, z2, d, "leaky_relu", valid=jc, cpad=dr, lowp="only" if lp else "no")
         dW2, grads[3] = ops.linear_wgrad(mode, dz2, d, [(a1, H1p)], with_bias=True)
         grads[2] = dW2[:, :H1]
         da1 = ops.linear_fwd(mode, _ksegs([(dz2, d)]), _wt(mode, W2.t(), [d]), H1, out_cols=H1p)

@@ -165,16 +165,18 @@ int gn_edge_rows(const int32_t* nbr, const int32_t* ovf_centre, const int32_t* o
 int gn_edge_gather_pre(const float* PQ, int32_t H1p, const int32_t* ic, const int32_t* jc, int64_t rows,
                        float* pre, void* stream);
 /* a[r, c] = act(gamma ? LayerNorm(z[r, :C]) : z[r, c]); 0 for C <= c < Cpad and for rows with valid[r] < 0;
- * act: 0 relu, 1 gelu (erf), 2 leaky relu (0.01), 3 identity; stats[r] = (mean, rstd) when gamma != NULL; Cpad <= 512. */
+ * act: 0 relu, 1 gelu (erf), 2 leaky relu (0.01), 3 identity; stats[r] = (mean, rstd) when gamma != NULL; Cpad <= 512.
+ * The result goes to a (fp32) and / or a_bf16 (the copy the MFMA GEMMs consume; either may be NULL, not both). */
 int gn_rownorm_act_fwd(const float* z, int64_t ldz, int32_t C, const int32_t* valid, const float* gamma,
                        const float* beta, float eps, int32_t act, float* a, int64_t lda, int32_t Cpad,
-                       float* stats, int64_t rows, void* stream);
+                       float* stats, int64_t rows, void* a_bf16, int64_t lda_bf16, void* stream);
 /* dz = d(loss)/dz given g = d(loss)/da (row gidx ? gidx[r] : r of g); with LayerNorm also the per-row terms
  * t_dy[rows, C], t_dyx[rows, C] whose column sums are dbeta and dgamma (gn_colsum). */
 int gn_rownorm_act_bwd(const float* g, int64_t ldg, const int32_t* gidx, const float* z, int64_t ldz, int32_t C,
                        const int32_t* valid, const float* gamma, const float* beta, const float* stats,
                        int32_t act, float* dz, int64_t lddz, int32_t Cpad, float* t_dy, float* t_dyx,
-                       int64_t rows, void* stream);
+                       int64_t rows, void* dz_bf16, int64_t lddz_bf16, void* stream);
+/* (dz fp32 and / or dz_bf16, as above) */
 /* out[i, :C] = sum over the slots (and the overflow row) of centre i of m[row, :C] */
 int gn_slot_sum(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, const int32_t* ovf_centre,
                 const int32_t* ovf_src, const int32_t* ovf_cnt, int32_t N, int32_t K, float* out, int64_t ldo,
