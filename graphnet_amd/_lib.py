@@ -50,11 +50,11 @@ SIGNATURES = {
     "gn_edgeconv_dw2": (I32, [I32, P, P, P, P, I32, I32, P, I32, I32, I32, P, I64, P, P, P, P]),
     "gn_edgeconv_dq_gather": (I32, [I32, P, I32, P, P, P, P, I32, P, I64, P]),
     "gn_edge_rows": (I32, [P, P, P, P, I32, I32, P, P, P]),
-    "gn_edge_gather_pre": (I32, [P, I32, P, P, I64, P, P]),
+    "gn_edge_gather_pre": (I32, [P, I32, P, P, I64, I32, P, I32, P]),
     "gn_rownorm_act_fwd": (I32, [P, I64, I32, P, P, P, c_float, I32, P, I64, I32, P, I64, P, I64, P]),
-    "gn_rownorm_act_bwd": (I32, [P, I64, P, P, I64, I32, P, P, P, P, I32, P, I64, I32, P, P, I64, P, I64, P]),
+    "gn_rownorm_act_bwd": (I32, [P, I64, P, P, I64, I32, P, P, P, P, I32, P, I64, I32, P, P, I64, P, I64, P, I32, P]),
     "gn_slot_sum": (I32, [P, I64, I32, P, P, P, P, I32, I32, P, I64, P]),
-    "gn_slot_reduce": (I32, [P, I64, I32, P, P, P, P, I32, I32, P, I32, P, I64, P, P, P, P]),
+    "gn_slot_reduce": (I32, [P, I64, I32, P, P, P, P, I32, I32, P, I32, P, I64, P, P, P, I32, P]),
     "gn_slot_reduce_bwd": (I32, [P, I64, I32, P, P, I64, I32, P, P, P, I64, I32, P]),
     "gn_pack_weights": (I32, [P, I32, P]),
     "gn_segment_pool_fwd": (I32, [P, I64, I32, P, I32, P, I32, P, P, P, P]),

@@ -194,10 +194,10 @@ int gn_edge_rows(const int32_t* nbr, const int32_t* ovf_centre, const int32_t* o
     return fail(gn::launch_edge_rows(make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), gn::edge_slots(K), ic, jc,
                                      S(stream)), "gn_edge_rows");
 }
-int gn_edge_gather_pre(const float* PQ, int32_t H1p, const int32_t* ic, const int32_t* jc, int64_t rows, float* pre,
-                       void* stream) {
-    hipError_t r = gn::launch_edge_gather_pre(PQ, H1p, ic, jc, rows, pre, S(stream));
-    if (r == hipErrorInvalidValue) return bad("gn_edge_gather_pre", "H1p % 4 != 0");
+int gn_edge_gather_pre(const float* PQ, int32_t H1p, const int32_t* ic, const int32_t* jc, int64_t rows, int32_t act,
+                       void* pre, int32_t pre_lowp, void* stream) {
+    hipError_t r = gn::launch_edge_gather_pre(PQ, H1p, ic, jc, rows, act, pre, pre_lowp, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_edge_gather_pre", "H1p % 4 (bf16: % 8) != 0, or act not in {2 leaky relu, 3 identity}");
     return fail(r, "gn_edge_gather_pre");
 }
 int gn_rownorm_act_fwd(const float* z, int64_t ldz, int32_t C, const int32_t* valid, const float* gamma, const float* beta,
@@ -212,10 +212,10 @@ int gn_rownorm_act_fwd(const float* z, int64_t ldz, int32_t C, const int32_t* va
 int gn_rownorm_act_bwd(const float* g, int64_t ldg, const int32_t* gidx, const float* z, int64_t ldz, int32_t C,
                        const int32_t* valid, const float* gamma, const float* beta, const float* stats, int32_t act,
                        float* dz, int64_t lddz, int32_t Cpad, float* t_dy, float* t_dyx, int64_t rows, void* dz_bf16,
-                       int64_t lddz_bf16, void* stream) {
+                       int64_t lddz_bf16, const int32_t* argrow, int32_t z_lowp, void* stream) {
     if (!dz && !dz_bf16) return bad("gn_rownorm_act_bwd", "dz and / or dz_bf16");
     hipError_t r = gn::launch_rownorm_act_bwd(g, ldg, gidx, z, ldz, C, valid, gamma, beta, stats, act, dz, lddz, Cpad, t_dy,
-                                              t_dyx, rows, dz_bf16, lddz_bf16, S(stream));
+                                              t_dyx, rows, dz_bf16, lddz_bf16, argrow, z_lowp, S(stream));
     if (r == hipErrorInvalidValue) return bad("gn_rownorm_act_bwd", "need 1 <= C <= Cpad <= 512, act in 0..3; LayerNorm needs beta, stats, t_dy, t_dyx");
     return fail(r, "gn_rownorm_act_bwd");
 }
@@ -229,11 +229,12 @@ int gn_slot_sum(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, cons
 
 int gn_slot_reduce(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, const int32_t* ovf_centre,
                    const int32_t* ovf_src, const int32_t* ovf_cnt, int32_t N, int32_t K, const int32_t* jc, int32_t aggr,
-                   float* out, int64_t ldo, int32_t* ovf_row, int32_t* deg, int32_t* argrow, void* stream) {
+                   float* out, int64_t ldo, int32_t* ovf_row, int32_t* deg, int32_t* argrow, int32_t post_act, void* stream) {
     if (K < 1 || K > 32) return bad("gn_slot_reduce", "need 1<=K<=32");
     hipError_t r = gn::launch_slot_reduce(m, ldm, C, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), gn::edge_slots(K),
-                                          jc, aggr, out, ldo, ovf_row, deg, argrow, S(stream));
-    if (r == hipErrorInvalidValue) return bad("gn_slot_reduce", "aggr in 0..2, ovf_row / deg required, argrow for max");
+                                          jc, aggr, out, ldo, ovf_row, deg, argrow, post_act, S(stream));
+    if (r == hipErrorInvalidValue)
+        return bad("gn_slot_reduce", "aggr in 0..2, ovf_row / deg required, argrow for max, post_act 3 (none) or 2 (leaky relu, max only)");
     return fail(r, "gn_slot_reduce");
 }
 int gn_slot_reduce_bwd(const float* gout, int64_t ldg, int32_t C, const int32_t* ic, const int32_t* jc, int64_t rows,

@@ -34,25 +34,6 @@ __global__ __launch_bounds__(256) void edge_rows_kernel(EdgeGraph g, int S, int*
     jc[t] = j;
 }
 
-// pre[r, 0:H1p] = P[ic[r]] + Q[jc[r]]  (PQ fp32 [N, 2*H1p]); rows without an edge -> 0
-__global__ __launch_bounds__(256) void edge_gather_pre_kernel(const float* __restrict__ PQ, int H1p,
-                                                              const int* __restrict__ ic, const int* __restrict__ jc,
-                                                              long long rows, float* __restrict__ pre) {
-    const int q4 = H1p >> 2;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long r = t / q4;
-    const int c = (int)(t % q4) * 4;
-    if (r >= rows) return;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const int j = jc[r];
-    if (j >= 0) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(PQ + (long long)ic[r] * 2 * H1p + c);
-        const f32x4 q = *reinterpret_cast<const f32x4*>(PQ + (long long)j * 2 * H1p + H1p + c);
-        v = p + q;
-    }
-    *reinterpret_cast<f32x4*>(pre + r * H1p + c) = v;
-}
-
 // ---------------------------------------------------------------- activations
 // ACT: 0 = relu, 1 = gelu (erf form, torch.nn.GELU() default), 2 = leaky relu (slope 0.01, torch default),
 //      3 = identity
@@ -69,6 +50,30 @@ template <int ACT> __device__ __forceinline__ float act_grad(float y) {
     else if constexpr (ACT == 2) return y > 0.0f ? 1.0f : 0.01f;
     else return 1.0f;
 }
+// pre[r, 0:H1p] = act(P[ic[r]] + Q[jc[r]])  (PQ fp32 [N, 2*H1p]); rows without an edge -> 0.  ACT = identity
+// gives the pre-activation (GELU / LayerNorm variants need it); a sign-preserving activation (leaky relu) can be
+// applied here directly - its derivative is recovered from the sign of the result, nothing else is stored.
+template <int ACT, typename OutT>
+__global__ __launch_bounds__(256) void edge_gather_pre_kernel(const float* __restrict__ PQ, int H1p,
+                                                              const int* __restrict__ ic, const int* __restrict__ jc,
+                                                              long long rows, OutT* __restrict__ pre) {
+    const int q4 = H1p >> 2;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long r = t / q4;
+    const int c = (int)(t % q4) * 4;
+    if (r >= rows) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int j = jc[r];
+    if (j >= 0) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(PQ + (long long)ic[r] * 2 * H1p + c);
+        const f32x4 q = *reinterpret_cast<const f32x4*>(PQ + (long long)j * 2 * H1p + H1p + c);
+        v = p + q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_fwd<ACT>(v[e]);
+    }
+    store4<OutT>(pre + r * H1p + c, v[0], v[1], v[2], v[3]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -138,8 +143,9 @@ __global__ __launch_bounds__(256) void rownorm_act_bwd_kernel(
     const float* __restrict__ z, long long ldz, int C, const int* __restrict__ valid,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats,
     float* __restrict__ dz, long long lddz, int Cpad, float* __restrict__ t_dy, float* __restrict__ t_dyx, long long rows,
-    __bf16* __restrict__ dz16, long long lddz16)
-{
+    __bf16* __restrict__ dz16, long long lddz16, const int* __restrict__ argrow, int z_lowp)
+{   // argrow (with gidx): max aggregation upstream - g[gidx[r], c] reaches row r only if argrow[gidx[r], c] == r
+    // z_lowp: z holds bf16 values (an activation output whose sign stands in for the pre-activation's)
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= rows) return;
@@ -154,10 +160,12 @@ __global__ __launch_bounds__(256) void rownorm_act_bwd_kernel(
         const int c = lane + 64 * k;
         xh[k] = 0.0f; dy[k] = 0.0f;
         if (ok && c < C) {
-            const float zz = z[r * ldz + c];
+            const float zz = z_lowp ? (float)reinterpret_cast<const __bf16*>(z)[r * ldz + c] : z[r * ldz + c];
             float y = zz;
             if constexpr (NORM) { xh[k] = (zz - mean) * rstd; y = xh[k] * gamma[c] + beta[c]; }
-            dy[k] = g[gr * ldg + c] * act_grad<ACT>(y);
+            float gv = g[gr * ldg + c];
+            if (argrow && argrow[gr * C + c] != (int)r) gv = 0.0f;
+            dy[k] = gv * act_grad<ACT>(y);
             if constexpr (NORM) {
                 const float dxh = dy[k] * gamma[c];
                 s1 += dxh;
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(256) void slot_sum_ovf_kernel(const float* __restri
 __global__ __launch_bounds__(256) void slot_reduce_kernel(const float* __restrict__ m, long long ldm, int C, int N, int S,
                                                           const int* __restrict__ jc, const int* __restrict__ ovf_row,
                                                           int aggr, float* __restrict__ out, long long ldo,
-                                                          int* __restrict__ argrow) {
+                                                          int* __restrict__ argrow, int post_act) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int i = (int)(t / C), c = (int)(t % C);
     if (i >= N) return;
@@ -230,6 +238,9 @@ __global__ __launch_bounds__(256) void slot_reduce_kernel(const float* __restric
     }
     if (aggr == 1) acc = cnt > 0 ? acc / (float)cnt : 0.0f;
     if (aggr == 2 && arg < 0) acc = 0.0f;
+    // a strictly increasing activation commutes with max (same value, same arg row): applied to the N x C result
+    // instead of the N*S x C edge rows
+    if (post_act == 2 && arg >= 0) acc = act_fwd<2>(acc);
     out[(long long)i * ldo + c] = acc;
     if (argrow) argrow[(long long)i * C + c] = arg;
 }
@@ -286,12 +297,15 @@ hipError_t launch_edge_rows(const EdgeGraph& g, int S, int* ic, int* jc, hipStre
     hipLaunchKernelGGL(edge_rows_kernel, dim3(gblocks(rows, 256)), dim3(256), 0, st, g, S, ic, jc, rows);
     return hipGetLastError();
 }
-hipError_t launch_edge_gather_pre(const float* PQ, int H1p, const int* ic, const int* jc, long long rows, float* pre,
-                                  hipStream_t st) {
+hipError_t launch_edge_gather_pre(const float* PQ, int H1p, const int* ic, const int* jc, long long rows, int act,
+                                  void* pre, int pre_lowp, hipStream_t st) {
     if (rows == 0) return hipSuccess;
-    if (H1p & 3) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(edge_gather_pre_kernel, dim3(gblocks(rows * (H1p >> 2), 256)), dim3(256), 0, st, PQ, H1p, ic, jc,
-                       rows, pre);
+    if ((H1p & 3) || (pre_lowp && (H1p & 7)) || (act != 2 && act != 3)) return hipErrorInvalidValue;
+    const dim3 grid(gblocks(rows * (H1p >> 2), 256)), block(256);
+#define GN_GP(ACT, T) hipLaunchKernelGGL((edge_gather_pre_kernel<ACT, T>), grid, block, 0, st, PQ, H1p, ic, jc, rows, (T*)pre)
+    if (act == 2) { if (pre_lowp) GN_GP(2, __bf16); else GN_GP(2, float); }
+    else { if (pre_lowp) GN_GP(3, __bf16); else GN_GP(3, float); }
+#undef GN_GP
     return hipGetLastError();
 }
 hipError_t launch_rownorm_act_fwd(const float* z, long long ldz, int C, const int* valid, const float* gamma,
@@ -311,13 +325,15 @@ hipError_t launch_rownorm_act_fwd(const float* z, long long ldz, int C, const in
 hipError_t launch_rownorm_act_bwd(const float* g, long long ldg, const int* gidx, const float* z, long long ldz, int C,
                                   const int* valid, const float* gamma, const float* beta, const float* stats, int act,
                                   float* dz, long long lddz, int Cpad, float* t_dy, float* t_dyx, long long rows,
-                                  void* dz16, long long lddz16, hipStream_t st) {
+                                  void* dz16, long long lddz16, const int* argrow, int z_lowp,
+                                  hipStream_t st) {
     if (rows == 0) return hipSuccess;
     const bool norm = gamma != nullptr;
-    if (C < 1 || Cpad < C || Cpad > RN_MAXC || act < 0 || act > 3 || (norm && (!beta || !stats || !t_dy || !t_dyx)))
+    if (C < 1 || Cpad < C || Cpad > RN_MAXC || act < 0 || act > 3 || (norm && (!beta || !stats || !t_dy || !t_dyx)) ||
+        (argrow && !gidx) || (z_lowp && norm))
         return hipErrorInvalidValue;
     const dim3 grid(gblocks(rows, 4)), block(256);
-#define GN_RN_BWD(NRM, ACT) hipLaunchKernelGGL((rownorm_act_bwd_kernel<NRM, ACT>), grid, block, 0, st, g, ldg, gidx, z, ldz, C, valid, gamma, beta, stats, dz, lddz, Cpad, t_dy, t_dyx, rows, (__bf16*)dz16, lddz16)
+#define GN_RN_BWD(NRM, ACT) hipLaunchKernelGGL((rownorm_act_bwd_kernel<NRM, ACT>), grid, block, 0, st, g, ldg, gidx, z, ldz, C, valid, gamma, beta, stats, dz, lddz, Cpad, t_dy, t_dyx, rows, (__bf16*)dz16, lddz16, argrow, z_lowp)
     if (norm) { if (act == 0) GN_RN_BWD(true, 0); else if (act == 1) GN_RN_BWD(true, 1); else if (act == 2) GN_RN_BWD(true, 2); else GN_RN_BWD(true, 3); }
     else { if (act == 0) GN_RN_BWD(false, 0); else if (act == 1) GN_RN_BWD(false, 1); else if (act == 2) GN_RN_BWD(false, 2); else GN_RN_BWD(false, 3); }
 #undef GN_RN_BWD
@@ -325,14 +341,16 @@ hipError_t launch_rownorm_act_bwd(const float* g, long long ldg, const int* gidx
 }
 // ovf_row, deg: int32[N] outputs (per graph, reusable); argrow: int32[N*C] output for aggr = max (else null)
 hipError_t launch_slot_reduce(const float* m, long long ldm, int C, const EdgeGraph& g, int S, const int* jc, int aggr,
-                              float* out, long long ldo, int* ovf_row, int* deg, int* argrow, hipStream_t st) {
+                              float* out, long long ldo, int* ovf_row, int* deg, int* argrow, int post_act,
+                              hipStream_t st) {
     if (g.N == 0) return hipSuccess;
     if (aggr < 0 || aggr > 2 || (aggr == 2 && !argrow) || !ovf_row || !deg) return hipErrorInvalidValue;
+    if (post_act != 3 && !(post_act == 2 && aggr == 2)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ovf_row_kernel, dim3(gblocks(g.N, 256)), dim3(256), 0, st, g, ovf_row);
     if (g.ovf_cnt) hipLaunchKernelGGL(ovf_row_fill_kernel, dim3(gblocks(g.N, 256)), dim3(256), 0, st, g, ovf_row);
     hipLaunchKernelGGL(centre_degree_kernel, dim3(gblocks(g.N, 256)), dim3(256), 0, st, jc, g.N, S, ovf_row, deg);
     hipLaunchKernelGGL(slot_reduce_kernel, dim3(gblocks((long long)g.N * C, 256)), dim3(256), 0, st, m, ldm, C, g.N, S, jc,
-                       ovf_row, aggr, out, ldo, argrow);
+                       ovf_row, aggr, out, ldo, argrow, post_act);
     return hipGetLastError();
 }
 hipError_t launch_slot_reduce_bwd(const float* gout, long long ldg, int C, const int* ic, const int* jc, long long rows,

@@ -49,17 +49,18 @@ hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_
                             const int* hubs, const int* nhubs, int N, void* dQ, long long ldq, hipStream_t st);
 // generic.hip
 hipError_t launch_edge_rows(const EdgeGraph& g, int S, int* ic, int* jc, hipStream_t st);
-hipError_t launch_edge_gather_pre(const float* PQ, int H1p, const int* ic, const int* jc, long long rows, float* pre,
-                                  hipStream_t st);
+hipError_t launch_edge_gather_pre(const float* PQ, int H1p, const int* ic, const int* jc, long long rows, int act,
+                                  void* pre, int pre_lowp, hipStream_t st);
 hipError_t launch_rownorm_act_fwd(const float* z, long long ldz, int C, const int* valid, const float* gamma,
                                   const float* beta, float eps, int act, float* a, long long lda, int Cpad, float* stats,
                                   long long rows, void* a16, long long lda16, hipStream_t st);
 hipError_t launch_rownorm_act_bwd(const float* g, long long ldg, const int* gidx, const float* z, long long ldz, int C,
                                   const int* valid, const float* gamma, const float* beta, const float* stats, int act,
                                   float* dz, long long lddz, int Cpad, float* t_dy, float* t_dyx, long long rows,
-                                  void* dz16, long long lddz16, hipStream_t st);
+                                  void* dz16, long long lddz16, const int* argrow, int z_lowp, hipStream_t st);
 hipError_t launch_slot_reduce(const float* m, long long ldm, int C, const EdgeGraph& g, int S, const int* jc, int aggr,
-                              float* out, long long ldo, int* ovf_row, int* deg, int* argrow, hipStream_t st);
+                              float* out, long long ldo, int* ovf_row, int* deg, int* argrow, int post_act,
+                              hipStream_t st);
 hipError_t launch_slot_reduce_bwd(const float* gout, long long ldg, int C, const int* ic, const int* jc, long long rows,
                                   int aggr, const int* deg, const int* argrow, float* grows, long long ldr, int Cpad,
                                   hipStream_t st);

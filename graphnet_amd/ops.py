@@ -459,12 +459,13 @@ def edge_rows(g: NeighbourTable) -> Tuple[Tensor, Tensor]:
     return ic, jc
 
 
-def edge_gather_pre(PQ: Tensor, H1p: int, ic: Tensor, jc: Tensor) -> Tensor:
+def edge_gather_pre(PQ: Tensor, H1p: int, ic: Tensor, jc: Tensor, act: str = "identity", lowp: bool = False) -> Tensor:
+    """Edge rows ``act(P[ic] + Q[jc])`` (``act``: "identity" or "leaky_relu"), fp32 or bf16 (``lowp``)."""
     _need(PQ, torch.float32, "PQ")
     R = int(ic.shape[0])
-    pre = torch.empty((R, H1p), dtype=torch.float32, device=PQ.device)
+    pre = torch.empty((R, H1p), dtype=torch.bfloat16 if lowp else torch.float32, device=PQ.device)
     with _timed("generic_edge"):
-        _lib.check(_lib.lib().gn_edge_gather_pre(_p(PQ), H1p, _p(ic), _p(jc), R, _p(pre), _st()))
+        _lib.check(_lib.lib().gn_edge_gather_pre(_p(PQ), H1p, _p(ic), _p(jc), R, ACT_CODES[act], _p(pre), int(lowp), _st()))
     return pre
 
 
@@ -487,10 +488,14 @@ def rownorm_act_fwd(z: Tensor, C: int, act: str, gamma: Optional[Tensor] = None,
 
 def rownorm_act_bwd(g: Tensor, z: Tensor, C: int, act: str, gamma: Optional[Tensor] = None, beta: Optional[Tensor] = None,
                     stats: Optional[Tensor] = None, valid: Optional[Tensor] = None, gidx: Optional[Tensor] = None,
-                    cpad: Optional[int] = None, lowp: str = "no"):
+                    cpad: Optional[int] = None, lowp: str = "no", argrow: Optional[Tensor] = None):
     """Backward of :func:`rownorm_act_fwd` -> (dz [R, cpad], dgamma | None, dbeta | None); ``lowp`` as there
-    ("only": dz is bf16, "both": dz is the pair (fp32, bf16))."""
-    _need(g, torch.float32, "g"); _need(z, torch.float32, "z")
+    ("only": dz is bf16, "both": dz is the pair (fp32, bf16)).  ``argrow`` (with ``gidx``): the rows fed a max
+    aggregation, ``g`` is routed to the arg rows only.  ``z`` may be a bf16 activation OUTPUT when the activation
+    preserves the sign (leaky relu without LayerNorm)."""
+    _need(g, torch.float32, "g")
+    if z.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("z must be fp32 or bf16")
     R = int(z.shape[0])
     cpad = C if cpad is None else cpad
     dz = torch.empty((R, cpad), dtype=torch.float32, device=z.device) if lowp != "only" else None
@@ -504,7 +509,8 @@ def rownorm_act_bwd(g: Tensor, z: Tensor, C: int, act: str, gamma: Optional[Tens
     with _timed("generic_rows"):
         _lib.check(_lib.lib().gn_rownorm_act_bwd(_p(g), _rows(g, "g"), _p(gidx), _p(z), _rows(z, "z"), C, _p(valid),
                                                  _p(gamma), _p(beta), _p(stats), ACT_CODES[act], _p(dz), cpad, cpad,
-                                                 _p(t1), _p(t2), R, _p(dz16), cpad, _st()))
+                                                 _p(t1), _p(t2), R, _p(dz16), cpad, _p(argrow),
+                                                 int(z.dtype == torch.bfloat16), _st()))
     res = dz if lowp == "no" else dz16 if lowp == "only" else (dz, dz16)
     if gamma is None:
         return res, None, None
@@ -522,8 +528,9 @@ def slot_sum(m: Tensor, C: int, g: NeighbourTable) -> Tensor:
 AGGR_CODES = {"add": 0, "sum": 0, "mean": 1, "max": 2}
 
 
-def slot_reduce(m: Tensor, C: int, g: NeighbourTable, aggr: str):
-    """Aggregate the edge rows of every centre (add / mean / max) -> (out [N, C], aux for the backward)."""
+def slot_reduce(m: Tensor, C: int, g: NeighbourTable, aggr: str, post_act: str = "identity"):
+    """Aggregate the edge rows of every centre (add / mean / max) -> (out [N, C], aux for the backward).
+    ``post_act="leaky_relu"`` (max only): ``leaky(max_j m_j)`` = ``max_j leaky(m_j)`` with the same arg rows."""
     _need(m, torch.float32, "m")
     ic, jc = edge_rows(g)
     dev = m.device
@@ -534,7 +541,7 @@ def slot_reduce(m: Tensor, C: int, g: NeighbourTable, aggr: str):
     argrow = torch.empty(max(g.N * C, 1), dtype=torch.int32, device=dev) if code == 2 else None
     with _timed("generic_edge"):
         _lib.check(_lib.lib().gn_slot_reduce(_p(m), _rows(m, "m"), C, *g.c_args(), _p(jc), code, _p(out), C, _p(ovf_row),
-                                             _p(deg), _p(argrow), _st()))
+                                             _p(deg), _p(argrow), ACT_CODES[post_act], _st()))
     return out, (deg, argrow)
 
 

@@ -58,12 +58,12 @@ class _DynTransFunction(torch.autograd.Function):
         bpq[:H1] = b1
         PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), _wt(mode, Wpq, [Fin]), 2 * H1p, bias=bpq)
         ic, jc = ops.edge_rows(g)
-        pre1 = ops.edge_gather_pre(PQ, H1p, ic, jc)
         lp = mode == ops.MODE_BF16                  # GEMM-only operands are produced in bf16 (weights-stationary GEMM)
-        a1, _ = ops.rownorm_act_fwd(pre1, H1, "leaky_relu", valid=jc, cpad=H1p, lowp="only" if lp else "no")
+        # leaky relu preserves the sign: a1 is produced by the gather itself and its derivative is read off a1's
+        # sign in the backward (no pre-activation tensor); the second one commutes with the max aggregation
+        a1 = ops.edge_gather_pre(PQ, H1p, ic, jc, act="leaky_relu", lowp=lp)
         z2 = ops.linear_fwd(mode, [(a1, H1p)], _wt(mode, W2, [H1]), d, bias=b2.contiguous(), out_cols=dr)
-        m, _ = ops.rownorm_act_fwd(z2, d, "leaky_relu", valid=jc, cpad=dr)
-        conv, aux = ops.slot_reduce(m, d, g, "max")
+        conv, aux = ops.slot_reduce(z2, d, g, "max", post_act="leaky_relu")
         residual = Fin == d                                             # layers.py:183-186
         r = conv.add_(x) if residual else conv
         y0, st0 = ops.rownorm_act_fwd(r, d, "identity", g0, be0, lowp="both" if lp else "no")      # self.norm1
@@ -94,14 +94,14 @@ class _DynTransFunction(torch.autograd.Function):
             ops.linear_fwd(mode, _ksegs([(h, F)]), _wt(mode, Wl2, [F]), d, bias=bl2.contiguous(), out=z3, accum=True)
         y2, st2 = ops.rownorm_act_fwd(z3, d, "identity", g2, be2)
         ctx.cfg, ctx.p = cfg, p
-        ctx.saved = (xin, Fin, pre1, a1, z2, aux, residual, r, st0, y0g, qkv, att, lse2, z1, st1, y1g, h, z3, st2)
+        ctx.saved = (xin, Fin, a1, z2, aux, residual, r, st0, y0g, qkv, att, lse2, z1, st1, y1g, h, z3, st2)
         return y2
 
     @staticmethod
     def backward(ctx, gy: Tensor):  # type: ignore[override]
         cfg, p = ctx.cfg, ctx.p
         (W1, b1, W2, b2, g0, be0, Win, bin_, Wout, bout, Wl1, bl1, Wl2, bl2, g1, be1, g2, be2) = p
-        (xin, Fin, pre1, a1, z2, aux, residual, r, st0, y0, qkv, att, lse2, z1, st1, y1, h, z3, st2) = ctx.saved
+        (xin, Fin, a1, z2, aux, residual, r, st0, y0, qkv, att, lse2, z1, st1, y1, h, z3, st2) = ctx.saved
         mode, g, H = cfg["mode"], cfg["graph"], cfg["n_head"]
         ptr, plan = cfg["ptr"], cfg["plan"]
         dev = xin.device
@@ -138,12 +138,12 @@ class _DynTransFunction(torch.autograd.Function):
         dres, grads[4], grads[5] = ops.rownorm_act_bwd(dz1, r, d, "identity", g0, be0, st0)
         # EdgeConvTito
         ic, jc = ops.edge_rows(g)
-        grows = ops.slot_reduce_bwd(dres, d, g, "max", aux, cpad=dr)
-        dz2, _, _ = ops.rownorm_act_bwd(grows, z2, d, "leaky_relu", valid=jc, cpad=dr, lowp="only" if lp else "no")
+        dz2, _, _ = ops.rownorm_act_bwd(dres, z2, d, "leaky_relu", valid=jc, gidx=ic, argrow=aux[1], cpad=dr,
+                                        lowp="only" if lp else "no")        # max routing + leaky' in one pass
         dW2, grads[3] = ops.linear_wgrad(mode, dz2, d, [(a1, H1p)], with_bias=True)
         grads[2] = dW2[:, :H1]
         da1 = ops.linear_fwd(mode, _ksegs([(dz2, d)]), _wt(mode, W2.t(), [d]), H1, out_cols=H1p)
-        dpre1, _, _ = ops.rownorm_act_bwd(da1, pre1, H1, "leaky_relu", valid=jc, cpad=H1p)
+        dpre1, _, _ = ops.rownorm_act_bwd(da1, a1, H1, "leaky_relu", valid=jc, cpad=H1p)
         dPQ = torch.empty((N, 2 * H1p), dtype=torch.float32, device=dev)
         dPQ[:, :H1p] = ops.slot_sum(dpre1, H1p, g)
         ops.edgeconv_dq_gather(ops.MODE_F32, g, dpre1, H1p, dPQ[:, H1p:])

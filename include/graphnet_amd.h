@@ -161,9 +161,11 @@ int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int
 /* ic[r], jc[r] = centre / source of edge row r (jc = -1: empty slot), r < N*S + N */
 int gn_edge_rows(const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src, const int32_t* ovf_cnt,
                  int32_t N, int32_t K, int32_t* ic, int32_t* jc, void* stream);
-/* pre[r, :H1p] = P[ic[r]] + Q[jc[r]] (PQ fp32 [N, 2*H1p]), 0 for empty slots */
-int gn_edge_gather_pre(const float* PQ, int32_t H1p, const int32_t* ic, const int32_t* jc, int64_t rows,
-                       float* pre, void* stream);
+/* pre[r, :H1p] = act(P[ic[r]] + Q[jc[r]]) (PQ fp32 [N, 2*H1p]), 0 for empty slots; act 3 (identity: the
+ * pre-activation) or 2 (leaky relu applied at once; its derivative is recovered from the result's sign);
+ * pre fp32, or bf16 when pre_lowp */
+int gn_edge_gather_pre(const float* PQ, int32_t H1p, const int32_t* ic, const int32_t* jc, int64_t rows, int32_t act,
+                       void* pre, int32_t pre_lowp, void* stream);
 /* a[r, c] = act(gamma ? LayerNorm(z[r, :C]) : z[r, c]); 0 for C <= c < Cpad and for rows with valid[r] < 0;
  * act: 0 relu, 1 gelu (erf), 2 leaky relu (0.01), 3 identity; stats[r] = (mean, rstd) when gamma != NULL; Cpad <= 512.
  * The result goes to a (fp32) and / or a_bf16 (the copy the MFMA GEMMs consume; either may be NULL, not both). */
@@ -175,8 +177,10 @@ int gn_rownorm_act_fwd(const float* z, int64_t ldz, int32_t C, const int32_t* va
 int gn_rownorm_act_bwd(const float* g, int64_t ldg, const int32_t* gidx, const float* z, int64_t ldz, int32_t C,
                        const int32_t* valid, const float* gamma, const float* beta, const float* stats,
                        int32_t act, float* dz, int64_t lddz, int32_t Cpad, float* t_dy, float* t_dyx,
-                       int64_t rows, void* dz_bf16, int64_t lddz_bf16, void* stream);
-/* (dz fp32 and / or dz_bf16, as above) */
+                       int64_t rows, void* dz_bf16, int64_t lddz_bf16, const int32_t* argrow, int32_t z_lowp,
+                       void* stream);
+/* (dz fp32 and / or dz_bf16, as above.  argrow != NULL (needs gidx): the rows fed a max aggregation
+ * (gn_slot_reduce) - g[gidx[r], c] reaches row r only where argrow[gidx[r]*C + c] == r.  z_lowp: z holds bf16.) */
 /* out[i, :C] = sum over the slots (and the overflow row) of centre i of m[row, :C] */
 int gn_slot_sum(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, const int32_t* ovf_centre,
                 const int32_t* ovf_src, const int32_t* ovf_cnt, int32_t N, int32_t K, float* out, int64_t ldo,
@@ -189,7 +193,9 @@ int gn_slot_sum(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, cons
 int gn_slot_reduce(const float* m, int64_t ldm, int32_t C, const int32_t* nbr, const int32_t* ovf_centre,
                    const int32_t* ovf_src, const int32_t* ovf_cnt, int32_t N, int32_t K, const int32_t* jc,
                    int32_t aggr, float* out, int64_t ldo, int32_t* ovf_row, int32_t* deg, int32_t* argrow,
-                   void* stream);
+                   int32_t post_act, void* stream);
+/* (post_act 3: none; 2: leaky relu applied to the max - a strictly increasing activation commutes with max, so
+ * the N*S edge rows need not be activated first) */
 int gn_slot_reduce_bwd(const float* gout, int64_t ldg, int32_t C, const int32_t* ic, const int32_t* jc,
                        int64_t rows, int32_t aggr, const int32_t* deg, const int32_t* argrow, float* grows,
                        int64_t ldr, int32_t Cpad, void* stream);
