@@ -11,6 +11,7 @@ from .model import Model, ModelConfig  # noqa: F401
 from .graphs import GraphDefinition, KNNEdges, KNNGraph, NodesAsPulses  # noqa: F401
 from .gnn import GNN, DynEdge, DynEdgeConv, DynEdgeJINST  # noqa: F401
 from .tito import DynEdgeTITO, DynTrans  # noqa: F401
+from .particlenet import ParticleNeT  # noqa: F401
 from .standard_model import (  # noqa: F401
     EnergyReconstruction, IdentityTask, LogCoshLoss, LossFunction, MSELoss, PiecewiseLinearLR,
     StandardLearnedTask, StandardModel, Task,

@@ -61,6 +61,11 @@ SIGNATURES = {
     "gn_segment_pool_bwd": (I32, [P, I32, P, P, I32, P, I32, P, P, P, I64, P, I64, I32, P]),
     "gn_attention_fwd": (I32, [I32, P, I64, I32, I32, P, P, I32, I32, P, I64, P, U32, U32, P]),
     "gn_attention_bwd": (I32, [I32, P, I64, I32, I32, P, P, I32, I32, P, I64, P, I64, P, P, P, I64, U32, U32, P]),
+    "gn_bn_blocks": (I64, [I64]),
+    "gn_bn_sums": (I32, [I32, I32, P, I64, I64, I32, P, P, I64, P, P, P, P, P, P, P]),
+    "gn_bn_finalize": (I32, [P, P, I32, c_float, P, P, P, P]),
+    "gn_bn_act_fwd": (I32, [P, I64, I64, I32, P, P, P, P, P, I32, P, I64, I32, I32, P]),
+    "gn_bn_act_bwd": (I32, [P, I64, P, I64, I64, I32, P, P, P, P, P, P, P, I32, P, I64, I32, I32, P]),
     "gn_dropout": (I32, [P, I64, I32, P, I64, P, I64, I32, I64, I32, U32, U32, P]),
 }
 

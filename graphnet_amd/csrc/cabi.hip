@@ -295,4 +295,33 @@ int gn_dropout(const void* x, int64_t ldx, int32_t x_lowp, const float* res, int
     return fail(r, "gn_dropout");
 }
 
+
+int64_t gn_bn_blocks(int64_t rows) { return gn::bn_blocks(rows); }
+int gn_bn_sums(int32_t mode, int32_t act, const float* z, int64_t ldz, int64_t rows, int32_t C, const int32_t* valid,
+               const float* g, int64_t ldg, const float* mean, const float* rstd, const float* gamma, const float* beta,
+               float* part, float* sums, void* stream) {
+    hipError_t r = gn::launch_bn_sums(mode, act, z, ldz, rows, C, valid, g, ldg, mean, rstd, gamma, beta, part, sums, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_bn_sums", "1 <= C <= 512, mode 0 / 1, act 0..3");
+    return fail(r, "gn_bn_sums");
+}
+int gn_bn_finalize(const float* sums, const int32_t* n_valid, int32_t C, float eps, float* mean, float* rstd,
+                   float* var_unbiased, void* stream) {
+    return fail(gn::launch_bn_finalize(sums, n_valid, C, eps, mean, rstd, var_unbiased, S(stream)), "gn_bn_finalize");
+}
+int gn_bn_act_fwd(const float* z, int64_t ldz, int64_t rows, int32_t C, const int32_t* valid, const float* mean,
+                  const float* rstd, const float* gamma, const float* beta, int32_t act, void* a, int64_t lda, int32_t Cpad,
+                  int32_t a_lowp, void* stream) {
+    hipError_t r = gn::launch_bn_act_fwd(z, ldz, rows, C, valid, mean, rstd, gamma, beta, act, a, lda, Cpad, a_lowp, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_bn_act_fwd", "1 <= C <= Cpad, Cpad % 4 == 0, act 0..3");
+    return fail(r, "gn_bn_act_fwd");
+}
+int gn_bn_act_bwd(const float* g, int64_t ldg, const float* z, int64_t ldz, int64_t rows, int32_t C, const int32_t* valid,
+                  const float* mean, const float* rstd, const float* gamma, const float* beta, const float* sums,
+                  const int32_t* n_valid, int32_t act, void* dz, int64_t lddz, int32_t Cpad, int32_t dz_lowp, void* stream) {
+    hipError_t r = gn::launch_bn_act_bwd(g, ldg, z, ldz, rows, C, valid, mean, rstd, gamma, beta, sums, n_valid, act, dz, lddz,
+                                         Cpad, dz_lowp, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_bn_act_bwd", "1 <= C <= Cpad, Cpad % 4 == 0, act 0..3, n_valid with sums");
+    return fail(r, "gn_bn_act_bwd");
+}
+
 }  // extern "C"

@@ -397,6 +397,168 @@ hipError_t launch_dropout(const void* x, long long ldx, int x_lowp, const float*
     else hipLaunchKernelGGL((dropout_kernel<float, float>), grid, block, 0, st, (const float*)x, ldx, res, ldres, (float*)y, ldy, rows, cols, dr);
     return hipGetLastError();
 }
+// ------------------------------------------------------------------------------ BatchNorm1d over edge rows
+// torch.nn.BatchNorm1d inside an EdgeConv MLP (ParticleNeT, models/gnn/particlenet.py:172-198) normalises every
+// column over ALL edges of the batch; the edge-row tensors here also hold empty slots (valid[r] < 0), which take
+// no part.  Forward: masked column sums of z and z^2 (BN_ROWS rows per workgroup, fixed-order partials) ->
+// bn_finalize (mean, rstd, unbiased variance) -> bn_act_fwd.  Backward: masked column sums of dy and dy*xhat ->
+// bn_act_bwd.  No atomics: two runs are bitwise identical.
+constexpr int BN_ROWS = 256;
+// part[blk][0:C] = sum_r f1, part[blk][C:2C] = sum_r f2 over the valid rows of the block, where
+//   MODE 0: f1 = z, f2 = z^2;   MODE 1: f1 = dy, f2 = dy * xhat with dy = g * act'(xhat*gamma+beta)
+template <int MODE, int ACT>
+__global__ __launch_bounds__(256) void bn_sums_kernel(const float* __restrict__ z, long long ldz, long long rows, int C,
+                                                      const int* __restrict__ valid, const float* __restrict__ g,
+                                                      long long ldg, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ part) {
+    __shared__ float red[2][4][RN_MAXC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long rbeg = (long long)blockIdx.x * BN_ROWS, rend = min(rows, rbeg + BN_ROWS);
+    float s1[RN_PER], s2[RN_PER];
+#pragma unroll
+    for (int k = 0; k < RN_PER; ++k) { s1[k] = 0.0f; s2[k] = 0.0f; }
+    for (long long r = rbeg + wave; r < rend; r += 4) {
+        if (valid && valid[r] < 0) continue;
+#pragma unroll
+        for (int k = 0; k < RN_PER; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) {
+                const float zz = z[r * ldz + c];
+                if constexpr (MODE == 0) { s1[k] += zz; s2[k] = fmaf(zz, zz, s2[k]); }
+                else {
+                    const float xh = (zz - mean[c]) * rstd[c];
+                    const float dy = g[r * ldg + c] * act_grad<ACT>(xh * gamma[c] + beta[c]);
+                    s1[k] += dy; s2[k] = fmaf(dy, xh, s2[k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RN_PER; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) { red[0][wave][c] = s1[k]; red[1][wave][c] = s2[k]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        part[(long long)blockIdx.x * 2 * C + c] = ((red[0][0][c] + red[0][1][c]) + red[0][2][c]) + red[0][3][c];
+        part[(long long)blockIdx.x * 2 * C + C + c] = ((red[1][0][c] + red[1][1][c]) + red[1][2][c]) + red[1][3][c];
+    }
+}
+// sums[0:C] = sum z, sums[C:2C] = sum z^2, n = *n_valid -> mean, rstd = 1/sqrt(var_biased + eps), var_unbiased
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums, const int* __restrict__ n_valid,
+                                                          int C, float eps, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, float* __restrict__ var_unbiased) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double n = (double)max(*n_valid, 1);
+    const double m = (double)sums[c] / n;
+    double var = (double)sums[C + c] / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (var_unbiased) var_unbiased[c] = (float)(n > 1.0 ? var * n / (n - 1.0) : var);
+}
+// a[r, c] = act((z - mean) * rstd * gamma + beta); 0 on empty rows and pad columns
+template <int ACT, typename OutT>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ z, long long ldz, long long rows, int C,
+                                                         const int* __restrict__ valid, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, OutT* __restrict__ a, long long lda,
+                                                         int Cpad) {
+    const int c4n = Cpad >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * c4n) return;
+    const long long r = idx / c4n;
+    const int c = (int)(idx % c4n) * 4;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!valid || valid[r] >= 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c + j < C) o[j] = act_fwd<ACT>((z[r * ldz + c + j] - mean[c + j]) * rstd[c + j] * gamma[c + j] + beta[c + j]);
+    }
+    store4<OutT>(a + r * lda + c, o[0], o[1], o[2], o[3]);
+}
+// dz = gamma * rstd * (dy - sums[c]/n - xhat * sums[C+c]/n)   (training; eval: dz = gamma * rstd * dy, sums == null)
+template <int ACT, typename OutT>
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict__ g, long long ldg, const float* __restrict__ z,
+                                                         long long ldz, long long rows, int C, const int* __restrict__ valid,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ sums, const int* __restrict__ n_valid,
+                                                         OutT* __restrict__ dz, long long lddz, int Cpad) {
+    const int c4n = Cpad >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * c4n) return;
+    const long long r = idx / c4n;
+    const int c = (int)(idx % c4n) * 4;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!valid || valid[r] >= 0) {
+        const float inv_n = sums ? 1.0f / (float)max(*n_valid, 1) : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c + j < C) {
+                const int cc = c + j;
+                const float xh = (z[r * ldz + cc] - mean[cc]) * rstd[cc];
+                const float dy = g[r * ldg + cc] * act_grad<ACT>(xh * gamma[cc] + beta[cc]);
+                const float corr = sums ? (sums[cc] + xh * sums[C + cc]) * inv_n : 0.0f;
+                o[j] = gamma[cc] * rstd[cc] * (dy - corr);
+            }
+    }
+    store4<OutT>(dz + r * lddz + c, o[0], o[1], o[2], o[3]);
+}
+
+int bn_blocks(long long rows) { return (int)((rows + BN_ROWS - 1) / BN_ROWS); }
+hipError_t launch_reduce_slabs(const float* slab, int nslab, long long count, float* out, int accum, hipStream_t st);
+
+// mode 0: forward moments of z; mode 1: backward sums (dbeta = sums[0:C], dgamma = sums[C:2C]).  part: bn_blocks*2C
+hipError_t launch_bn_sums(int mode, int act, const float* z, long long ldz, long long rows, int C, const int* valid,
+                          const float* g, long long ldg, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, float* part, float* sums, hipStream_t st) {
+    if (C < 1 || C > RN_MAXC || (mode != 0 && mode != 1) || act < 0 || act > 3) return hipErrorInvalidValue;
+    const int nb = bn_blocks(rows > 0 ? rows : 1);
+    const dim3 grid(nb), block(256);
+    if (mode == 0) hipLaunchKernelGGL((bn_sums_kernel<0, 3>), grid, block, 0, st, z, ldz, rows, C, valid, g, ldg, mean, rstd, gamma, beta, part);
+    else {
+#define GN_BNS(A) hipLaunchKernelGGL((bn_sums_kernel<1, A>), grid, block, 0, st, z, ldz, rows, C, valid, g, ldg, mean, rstd, gamma, beta, part)
+        if (act == 0) GN_BNS(0); else if (act == 1) GN_BNS(1); else if (act == 2) GN_BNS(2); else GN_BNS(3);
+#undef GN_BNS
+    }
+    return launch_reduce_slabs(part, nb, 2ll * C, sums, 0, st);
+}
+hipError_t launch_bn_finalize(const float* sums, const int* n_valid, int C, float eps, float* mean, float* rstd,
+                              float* var_unbiased, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(gblocks(C, 256)), dim3(256), 0, st, sums, n_valid, C, eps, mean, rstd, var_unbiased);
+    return hipGetLastError();
+}
+hipError_t launch_bn_act_fwd(const float* z, long long ldz, long long rows, int C, const int* valid, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta, int act, void* a, long long lda,
+                             int Cpad, int a_lowp, hipStream_t st) {
+    if (rows == 0) return hipSuccess;
+    if (C < 1 || Cpad < C || (Cpad & 3) || (a_lowp && (lda & 3)) || act < 0 || act > 3) return hipErrorInvalidValue;
+    const dim3 grid(gblocks(rows * (Cpad >> 2), 256)), block(256);
+#define GN_BNF(A, T) hipLaunchKernelGGL((bn_act_fwd_kernel<A, T>), grid, block, 0, st, z, ldz, rows, C, valid, mean, rstd, gamma, beta, (T*)a, lda, Cpad)
+#define GN_BNF2(A) { if (a_lowp) GN_BNF(A, __bf16); else GN_BNF(A, float); }
+    if (act == 0) GN_BNF2(0) else if (act == 1) GN_BNF2(1) else if (act == 2) GN_BNF2(2) else GN_BNF2(3)
+#undef GN_BNF2
+#undef GN_BNF
+    return hipGetLastError();
+}
+hipError_t launch_bn_act_bwd(const float* g, long long ldg, const float* z, long long ldz, long long rows, int C,
+                             const int* valid, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                             const float* sums, const int* n_valid, int act, void* dz, long long lddz, int Cpad, int dz_lowp,
+                             hipStream_t st) {
+    if (rows == 0) return hipSuccess;
+    if (C < 1 || Cpad < C || (Cpad & 3) || act < 0 || act > 3 || (sums && !n_valid)) return hipErrorInvalidValue;
+    const dim3 grid(gblocks(rows * (Cpad >> 2), 256)), block(256);
+#define GN_BNB(A, T) hipLaunchKernelGGL((bn_act_bwd_kernel<A, T>), grid, block, 0, st, g, ldg, z, ldz, rows, C, valid, mean, rstd, gamma, beta, sums, n_valid, (T*)dz, lddz, Cpad)
+#define GN_BNB2(A) { if (dz_lowp) GN_BNB(A, __bf16); else GN_BNB(A, float); }
+    if (act == 0) GN_BNB2(0) else if (act == 1) GN_BNB2(1) else if (act == 2) GN_BNB2(2) else GN_BNB2(3)
+#undef GN_BNB2
+#undef GN_BNB
+    return hipGetLastError();
+}
+
 hipError_t launch_slot_sum(const float* m, long long ldm, int C, const EdgeGraph& g, int S, float* out, long long ldo,
                            hipStream_t st) {
     if (g.N == 0) return hipSuccess;

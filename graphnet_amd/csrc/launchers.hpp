@@ -73,6 +73,20 @@ hipError_t launch_pool_fwd(const float* x, long long ldx, int C, const int* ptr,
 hipError_t launch_pool_bwd(const float* gout, int C, const int* ptr, const int* batch, int N, const int* codes, int ns,
                            const int* argmin, const int* argmax, const float* gate, long long ldgate, void* dx,
                            long long lddx, int dx_lowp, hipStream_t st);
+// generic.hip: BatchNorm1d over edge rows (masked by valid[r] >= 0)
+int bn_blocks(long long rows);
+hipError_t launch_bn_sums(int mode, int act, const float* z, long long ldz, long long rows, int C, const int* valid,
+                          const float* g, long long ldg, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, float* part, float* sums, hipStream_t st);
+hipError_t launch_bn_finalize(const float* sums, const int* n_valid, int C, float eps, float* mean, float* rstd,
+                              float* var_unbiased, hipStream_t st);
+hipError_t launch_bn_act_fwd(const float* z, long long ldz, long long rows, int C, const int* valid, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta, int act, void* a, long long lda,
+                             int Cpad, int a_lowp, hipStream_t st);
+hipError_t launch_bn_act_bwd(const float* g, long long ldg, const float* z, long long ldz, long long rows, int C,
+                             const int* valid, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                             const float* sums, const int* n_valid, int act, void* dz, long long lddz, int Cpad, int dz_lowp,
+                             hipStream_t st);
 // attn.hip  (lowp: qkv / out / dout / dqkv are bf16 and the MFMA kernels run; else fp32 on the vector ALU)
 hipError_t launch_attn_fwd(int lowp, const void* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
                            int B, int N, void* out, long long ldo, float* lse2, unsigned seed, unsigned thresh,

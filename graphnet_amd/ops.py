@@ -517,6 +517,54 @@ def rownorm_act_bwd(g: Tensor, z: Tensor, C: int, act: str, gamma: Optional[Tens
     return res, colsum(t2, C), colsum(t1, C)
 
 
+# BatchNorm1d over edge rows (include/graphnet_amd.h: gn_bn_*)
+def bn_stats(z: Tensor, C: int, valid: Optional[Tensor], n_valid: Tensor, eps: float):
+    """Training statistics over the valid rows -> (mean [C], rstd [C], var_unbiased [C])."""
+    _need(z, torch.float32, "z"); _need(n_valid, torch.int32, "n_valid")
+    R, dev = int(z.shape[0]), z.device
+    L = _lib.lib()
+    part = torch.empty(int(L.gn_bn_blocks(R)) * 2 * C, dtype=torch.float32, device=dev)
+    sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    mean, rstd, varu = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(3))
+    with _timed("generic_rows"):
+        _lib.check(L.gn_bn_sums(0, 3, _p(z), _rows(z, "z"), R, C, _p(valid), None, 0, None, None, None, None, _p(part),
+                                _p(sums), _st()))
+        _lib.check(L.gn_bn_finalize(_p(sums), _p(n_valid), C, float(eps), _p(mean), _p(rstd), _p(varu), _st()))
+    return mean, rstd, varu
+
+
+def bn_act_fwd(z: Tensor, C: int, valid: Optional[Tensor], mean: Tensor, rstd: Tensor, gamma: Tensor, beta: Tensor,
+               act: str, cpad: Optional[int] = None, lowp: bool = False) -> Tensor:
+    _need(z, torch.float32, "z")
+    R = int(z.shape[0])
+    cpad = C if cpad is None else cpad
+    a = torch.empty((R, cpad), dtype=torch.bfloat16 if lowp else torch.float32, device=z.device)
+    with _timed("generic_rows"):
+        _lib.check(_lib.lib().gn_bn_act_fwd(_p(z), _rows(z, "z"), R, C, _p(valid), _p(mean), _p(rstd), _p(gamma), _p(beta),
+                                            ACT_CODES[act], _p(a), cpad, cpad, int(lowp), _st()))
+    return a
+
+
+def bn_act_bwd(g: Tensor, z: Tensor, C: int, valid: Optional[Tensor], mean: Tensor, rstd: Tensor, gamma: Tensor,
+               beta: Tensor, act: str, n_valid: Optional[Tensor], training: bool = True, cpad: Optional[int] = None,
+               lowp: bool = False):
+    """-> (dz [R, cpad], dgamma [C], dbeta [C]); ``training=False``: statistics were constants (running stats)."""
+    _need(g, torch.float32, "g"); _need(z, torch.float32, "z")
+    R, dev = int(z.shape[0]), z.device
+    cpad = C if cpad is None else cpad
+    L = _lib.lib()
+    part = torch.empty(int(L.gn_bn_blocks(R)) * 2 * C, dtype=torch.float32, device=dev)
+    sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    dz = torch.empty((R, cpad), dtype=torch.bfloat16 if lowp else torch.float32, device=dev)
+    with _timed("generic_rows"):
+        _lib.check(L.gn_bn_sums(1, ACT_CODES[act], _p(z), _rows(z, "z"), R, C, _p(valid), _p(g), _rows(g, "g"), _p(mean),
+                                _p(rstd), _p(gamma), _p(beta), _p(part), _p(sums), _st()))
+        _lib.check(L.gn_bn_act_bwd(_p(g), _rows(g, "g"), _p(z), _rows(z, "z"), R, C, _p(valid), _p(mean), _p(rstd),
+                                   _p(gamma), _p(beta), _p(sums) if training else None, _p(n_valid) if training else None,
+                                   ACT_CODES[act], _p(dz), cpad, cpad, int(lowp), _st()))
+    return dz, sums[C:], sums[:C]
+
+
 def slot_sum(m: Tensor, C: int, g: NeighbourTable) -> Tensor:
     _need(m, torch.float32, "m")
     out = torch.empty((g.N, C), dtype=torch.float32, device=m.device)

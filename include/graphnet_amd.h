@@ -200,6 +200,27 @@ int gn_slot_reduce_bwd(const float* gout, int64_t ldg, int32_t C, const int32_t*
                        int64_t rows, int32_t aggr, const int32_t* deg, const int32_t* argrow, float* grows,
                        int64_t ldr, int32_t Cpad, void* stream);
 
+/* ---- BatchNorm1d inside an EdgeConv MLP (ParticleNeT, models/gnn/particlenet.py:172-198) ---- */
+/* torch.nn.BatchNorm1d over the edges of the batch = the rows r with valid[r] >= 0 of an edge-row tensor.
+ * Training forward: gn_bn_sums(mode 0) -> sums[2C] = (sum z, sum z^2); gn_bn_finalize -> mean, rstd (biased
+ * variance + eps), var_unbiased (for running_var); gn_bn_act_fwd -> a = act((z - mean) rstd gamma + beta) (fp32 or
+ * bf16, 0 on empty rows).  Eval: gn_bn_act_fwd with the running statistics.  Backward: gn_bn_sums(mode 1, g = dL/da)
+ * -> sums = (dbeta, dgamma); gn_bn_act_bwd -> dz (sums = NULL: eval-mode backward).  n_valid: DEVICE int[1], number
+ * of valid rows.  part: gn_bn_blocks(rows) * 2C floats of scratch.  Fixed-order reductions, no atomics. */
+int64_t gn_bn_blocks(int64_t rows);
+int gn_bn_sums(int32_t mode, int32_t act, const float* z, int64_t ldz, int64_t rows, int32_t C, const int32_t* valid,
+               const float* g, int64_t ldg, const float* mean, const float* rstd, const float* gamma, const float* beta,
+               float* part, float* sums, void* stream);
+int gn_bn_finalize(const float* sums, const int32_t* n_valid, int32_t C, float eps, float* mean, float* rstd,
+                   float* var_unbiased, void* stream);
+int gn_bn_act_fwd(const float* z, int64_t ldz, int64_t rows, int32_t C, const int32_t* valid, const float* mean,
+                  const float* rstd, const float* gamma, const float* beta, int32_t act, void* a, int64_t lda,
+                  int32_t Cpad, int32_t a_lowp, void* stream);
+int gn_bn_act_bwd(const float* g, int64_t ldg, const float* z, int64_t ldz, int64_t rows, int32_t C,
+                  const int32_t* valid, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                  const float* sums, const int32_t* n_valid, int32_t act, void* dz, int64_t lddz, int32_t Cpad,
+                  int32_t dz_lowp, void* stream);
+
 /* ---- operand copies of the weights ------------------------------------------------------- */
 /* One launch rewrites every padded / transposed / bf16 copy of the weights the kernels above consume
  * (what torch.nn.Linear does implicitly with its own weight).  desc: DEVICE int64[ndesc][10] =

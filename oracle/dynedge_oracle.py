@@ -475,3 +475,48 @@ class StandardModelOracle(torch.nn.Module):
     def loss(self, x, edge_index, batch, n_pulses, energy):
         pred = self.forward(x, edge_index, batch, n_pulses)
         return log_cosh_loss(pred, torch.log10(energy).unsqueeze(1))
+
+
+class ParticleNeTOracle(torch.nn.Module):
+    """CPU restatement of ``models/gnn/particlenet.py`` (layers l.172-213, forward l.228-244): DynEdgeConv blocks
+    with ``[Linear, BatchNorm1d, act] x L`` edge MLPs (torch's own BatchNorm1d over the E edge rows), mean
+    aggregation, k-NN re-clustering after every block, pooling, read-out with dropout."""
+
+    def __init__(self, nb_inputs: int, nb_neighbours: int = 16, features_subset=None, dynamic: bool = True,
+                 dynedge_layer_sizes=((64, 64, 64), (128, 128, 128), (256, 256, 256)), readout_layer_sizes=(256,),
+                 global_pooling_schemes=("mean",), activation_layer: str = "relu", add_batchnorm_layer: bool = True,
+                 dropout_readout: float = 0.1, knn_mode: str = "compat"):
+        super().__init__()
+        self._k, self._dynamic, self._knn_mode = nb_neighbours, dynamic, knn_mode
+        self._subset = features_subset if features_subset is not None else slice(0, 3)
+        self._pools = list(global_pooling_schemes) if global_pooling_schemes else None
+        act = torch.nn.ReLU() if activation_layer == "relu" else torch.nn.GELU()
+        self._conv_layers = torch.nn.ModuleList()
+        lat = nb_inputs
+        for sizes in dynedge_layer_sizes:
+            layers, ls = [], [lat] + list(sizes)
+            for ix, (a, b) in enumerate(zip(ls[:-1], ls[1:])):
+                layers.append(torch.nn.Linear(a * 2 if ix == 0 else a, b))
+                if add_batchnorm_layer:
+                    layers.append(torch.nn.BatchNorm1d(b))
+                layers.append(act)
+            self._conv_layers.append(_ConvHolder(torch.nn.Sequential(*layers)))
+            lat = ls[-1]
+        lat *= len(self._pools) if self._pools else 1
+        ro, ls = [], [lat] + list(readout_layer_sizes)
+        for a, b in zip(ls[:-1], ls[1:]):
+            ro += [torch.nn.Linear(a, b), act, torch.nn.Dropout(dropout_readout)]
+        self._readout = torch.nn.Sequential(*ro)
+
+    def forward(self, x, edge_index, batch, n_pulses, forced_edges: Optional[List[Tensor]] = None):
+        B = int(n_pulses.shape[0])
+        for l, conv in enumerate(self._conv_layers):
+            x = edge_conv(x, edge_index, conv.nn, "mean")
+            if self._dynamic:
+                if forced_edges is not None and l + 1 < len(forced_edges):
+                    edge_index = forced_edges[l + 1]
+                else:
+                    edge_index = knn_graph(x, self._k, batch, self._subset, self._knn_mode)
+        if self._pools:
+            x = torch.cat([GLOBAL_POOLINGS[s](x, batch, B) for s in self._pools], dim=1)
+        return self._readout(x)

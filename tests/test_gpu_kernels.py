@@ -635,3 +635,53 @@ def test_dynedge_as_embedded_in_deepice(oracle, name, mode, tol):
             assert rel_err(p.grad, po.grad) < 2e-3, f"{name}: grad {kn}"
         else:
             assert norm_err(p.grad, po.grad) < 5e-2, f"{name}: grad {kn}"
+
+
+@pytest.mark.parametrize("name,mode,tol", MODES)
+def test_particlenet_backbone(oracle, name, mode, tol):
+    """ParticleNeT (models/gnn/particlenet.py): three-layer edge MLPs with BatchNorm1d over the edges of the batch
+    (training: batch statistics + running-stat update; eval: running statistics), mean aggregation, 16 neighbours,
+    re-clustering after every block (teacher-forced on the graphs the device built), mean pooling, read-out."""
+    import graphnet_amd as g
+    b = _batch(6, seed=57)
+    b.x[3:25, :3] = b.x[2, :3]                  # > 17 pulses on one position: overflow rows with k = 16
+    kw = dict(dynedge_layer_sizes=[(32, 32, 32), (64, 64, 64)], readout_layer_sizes=[48], dropout_readout=0.0)
+    torch.manual_seed(12)
+    ref = oracle.ParticleNeTOracle(7, **kw)
+    m = g.ParticleNeT(7, **kw)
+    assert list(m.state_dict()) == list(ref.state_dict())
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).set_backend(dtype=name)
+    m.train(); ref.train()
+    y, trace = m(b.to(DEV), return_trace=True)
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
+    (y * w.to(DEV)).sum().backward()
+    bc = b.to("cpu")
+    forced = [t.edge_index().cpu() for t in trace["graphs"]]
+    assert torch.equal(forced[0], oracle.knn_graph(bc.x, 16, bc.batch, [0, 1, 2]))
+    yo = ref(bc.x, forced[0], bc.batch, bc.n_pulses, forced_edges=forced)
+    (yo * w).sum().backward()
+    assert rel_err(y, yo.detach()) < tol
+    if mode == 0:   # the re-clustered graph is the oracle's k-NN of the same coordinates
+        assert torch.equal(forced[1], oracle.knn_graph(trace["conv_out"][0].detach().cpu(), 16, bc.batch, [0, 1, 2]))
+    for (kn, p), (_, po) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, kn
+        if po.grad.abs().max() < 1e-5:      # a Linear bias in front of BatchNorm has an exactly-zero gradient:
+            # both sides hold rounding noise only (bf16: the cancellation of ~1e5 rounded terms of size 1e-2)
+            assert p.grad.abs().max() < (1e-5 if mode == 0 else 5e-3), kn
+        elif mode == 0:
+            assert rel_err(p.grad, po.grad) < 2e-3, f"{name}: grad {kn}"
+        else:
+            assert norm_err(p.grad, po.grad) < 8e-2, f"{name}: grad {kn}"
+    sd, sdo = m.state_dict(), ref.state_dict()
+    for k in sd:
+        if "running" in k or "num_batches" in k:
+            assert rel_err(sd[k].float(), sdo[k].float()) < (1e-4 if mode == 0 else 2e-2), k
+    # eval mode: running statistics
+    m.eval(); ref.eval()
+    with torch.no_grad():
+        ye, tre = m(b.to(DEV), return_trace=True)
+        b.to("cpu")
+        forced_e = [t.edge_index().cpu() for t in tre["graphs"]]      # eval-mode features give their own graphs
+        yeo = ref(b.x, forced_e[0], b.batch, b.n_pulses, forced_edges=forced_e)
+    assert rel_err(ye, yeo) < (2e-4 if mode == 0 else 3e-2)
