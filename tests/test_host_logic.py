@@ -327,3 +327,46 @@ def test_task_heads_and_losses():
     good = sm.VonMisesFisher2DLoss()(torch.tensor([[0.3, 5.0], [1.0, 5.0]]), ang)
     bad = sm.VonMisesFisher2DLoss()(torch.tensor([[0.3 + np.pi, 5.0], [1.0 + np.pi, 5.0]]), ang)
     assert float(good) < float(bad) and abs(float(bad - good) - 10.0) < 1e-4      # 2 * kappa
+
+
+def test_sibling_backbones_have_the_reference_parameter_layout():
+    """State-dict keys and shapes of DynEdgeTITO / ParticleNeT / DynEdgeJINST equal the oracle's, whose modules are
+    built exactly as the reference builds them (``dynedge_kaggle_tito.py:140-196``, ``particlenet.py:172-213``,
+    ``dynedge_jinst.py:49-152``); torch's own TransformerEncoderLayer / BatchNorm1d supply the inner names."""
+    import graphnet_amd as g
+    from oracle import dynedge_oracle, tito_oracle
+    pairs = [
+        (g.DynEdgeTITO(7, n_head=4, dyntrans_layer_sizes=[(64, 64), (64, 64)]),
+         tito_oracle.DynEdgeTITOOracle(7, n_head=4, dyntrans_layer_sizes=[(64, 64), (64, 64)])),
+        (g.ParticleNeT(7), dynedge_oracle.ParticleNeTOracle(7)),
+        (g.DynEdgeJINST(7), dynedge_oracle.DynEdgeJINSTOracle(7)),
+    ]
+    for ours, ref in pairs:
+        a, b = ours.state_dict(), ref.state_dict()
+        assert list(a) == list(b), type(ours).__name__
+        assert all(a[k].shape == b[k].shape for k in a), type(ours).__name__
+    keys = list(pairs[1][0].state_dict())
+    assert "_conv_layers.0.nn.1.running_mean" in keys and "_conv_layers.2.nn.7.num_batches_tracked" in keys
+    assert pairs[0][0].nb_outputs == 128 and pairs[1][0].nb_outputs == 256
+    with pytest.raises(RuntimeError, match="MI355X"):
+        pairs[1][0](type("D", (), {"x": __import__("torch").zeros(3, 7)})())
+
+
+def test_dropout_keep_rule_replica_properties():
+    """The numpy replica of the stateless dropout rule (``include/graphnet_amd.h: gn_dropout``): deterministic,
+    seed- and position-dependent, keep rate = 1 - p to within sampling error, threshold arithmetic."""
+    from oracle import tito_oracle
+    from graphnet_amd import ops
+    r = np.arange(2000)[:, None]
+    c = np.arange(256)[None, :]
+    th = ops.drop_thresh(0.1)
+    assert th == round(0.1 * 2 ** 32) and ops.drop_thresh(0.0) == 0
+    k1 = tito_oracle.keep_mask(123, r, c, th)
+    assert np.array_equal(k1, tito_oracle.keep_mask(123, r, c, th))
+    assert abs(k1.mean() - 0.9) < 3e-3
+    k2 = tito_oracle.keep_mask(124, r, c, th)
+    assert 0.15 < (k1 != k2).mean() < 0.21                  # independent streams: 2 p (1 - p) = 0.18
+    assert tito_oracle.keep_mask(5, r, c, 0).all()
+    assert abs(k1[:, ::2].mean() - k1[:, 1::2].mean()) < 5e-3 and abs(k1[::2].mean() - k1[1::2].mean()) < 5e-3
+    with pytest.raises(ValueError):
+        ops.drop_thresh(1.0)
