@@ -9,6 +9,8 @@ the kernels); the tiny read-out MLP on ``[B, 1024]`` stays in torch.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Any, List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -186,6 +188,17 @@ class _DynEdgeFunction(torch.autograd.Function):
         graphs, PQs, masks = [], [], []
         knn_coords: List[Tensor] = []          # fp32 coordinates each re-built graph was computed from
         plan = None
+        # Second HIP stream: the k-NN of layer l+1 (vector-ALU bound) runs beside the P|Q GEMM of layer l+1 (HBM
+        # bound, needs only the features), the reverse adjacency of every graph (needed by the backward only)
+        # beside the edge kernel.  Tensors crossing streams are kept alive until the streams have joined.
+        side = cfg.get("side_stream")
+        main = torch.cuda.current_stream() if side is not None else None
+        keep: List[Any] = []
+        graph_ready = None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                g.build_reverse()
         for l, (W1, b1, W2, b2) in enumerate(conv_p):
             xin, Fin = xs[-1]
             H1, H2 = int(W1.shape[0]), int(W2.shape[0])
@@ -199,6 +212,9 @@ class _DynEdgeFunction(torch.autograd.Function):
             wb.copy(bpq[:H1], b1)
             PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), Wpq, 2 * H1p, bias=bpq, out_lowp=lowp)
             W2p = _packed(wb, ("W2p", l), W2, dt)
+            if graph_ready is not None:
+                main.wait_event(graph_ready)                 # this layer's graph was built on the side stream
+                graph_ready = None
             if l + 1 < nconv:
                 cols = _subset_cols(cfg["features_subset"], H2)
                 if plan is None:
@@ -206,8 +222,17 @@ class _DynEdgeFunction(torch.autograd.Function):
                 if lowp and len(cols) <= 8:
                     # bf16 activations: the k-NN coordinates leave the kernel as a separate fp32 copy
                     out, mask, coords = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2.contiguous(), H2, coord_cols=cols)
-                    g_next = ops.knn_graph(coords, list(range(len(cols))), batch, ptr, cfg["k"],
-                                           strict=cfg["strict"], plan=plan)
+                    if side is not None:
+                        keep.append(coords)
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            g_next = ops.knn_graph(coords, list(range(len(cols))), batch, ptr, cfg["k"],
+                                                   strict=cfg["strict"], plan=plan)
+                            graph_ready = side.record_event()
+                            g_next.build_reverse()
+                    else:
+                        g_next = ops.knn_graph(coords, list(range(len(cols))), batch, ptr, cfg["k"],
+                                               strict=cfg["strict"], plan=plan)
                     knn_coords.append(coords[:, :len(cols)])
                 else:
                     out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2.contiguous(), H2)
@@ -231,6 +256,9 @@ class _DynEdgeFunction(torch.autograd.Function):
             ys.append((y, int(W.shape[0])))
             segs = [ys[-1]]
         wb.end("fwd", x.device)
+        if side is not None:
+            main.wait_stream(side)                           # join: everything the side stream produced is complete
+        del keep
         y_last, P = ys[-1]
         ctx.cfg, ctx.xs, ctx.graphs, ctx.PQs, ctx.masks, ctx.ys = cfg, xs, graphs, PQs, masks, ys
         ctx.params = params
@@ -647,7 +675,7 @@ class DynEdge(GNN):
 
     # ------------------------------------------------------------------ backend control
     def set_backend(self, *, dtype: str = "bf16", knn_mode: str = "compat",
-                    graph_columns: Optional[List[int]] = None) -> "DynEdge":
+                    graph_columns: Optional[List[int]] = None, overlap: Optional[bool] = None) -> "DynEdge":
         """``dtype``: "bf16" (MFMA bf16 operands, fp32 accumulate) or "fp32" (exact-f32 MFMA,
         parity mode).  ``knn_mode``: "compat" (k+1-with-self then mask, as knn_graph) or
         "strict".  ``graph_columns``: columns for the layer-1 k-NN when the batch carries no
@@ -656,7 +684,25 @@ class DynEdge(GNN):
         self._knn_strict = {"compat": False, "strict": True}[knn_mode]
         if graph_columns is not None:
             self._graph_columns = list(graph_columns)
+        if overlap is not None:     # graph building on a second HIP stream beside the GEMM / edge kernels (default on)
+            self._overlap = bool(overlap)
         return self
+
+    def _side_stream(self, device, n_pulses: int) -> Optional["torch.cuda.Stream"]:
+        """Second HIP stream for graph building (``set_backend(overlap=...)``, env ``GN_NO_OVERLAP=1`` disables);
+        never during hipGraph capture.  Default: on from 2^18 pulses per batch - measured +1.1 % at 623k pulses
+        (B = 4096), -1.8 % at 158k (B = 1024: the extra events and the shared vector ALU cost more than the overlap
+        returns)."""
+        overlap = getattr(self, "_overlap", None)
+        if overlap is None:
+            overlap = n_pulses >= (1 << 18)
+        if not overlap or os.environ.get("GN_NO_OVERLAP") == "1" or torch.cuda.is_current_stream_capturing():
+            return None
+        st = self.__dict__.get("_side")
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            self.__dict__["_side"] = st
+        return st
 
     def _is_generic(self) -> bool:
         """GELU and / or LayerNorm: the unfused kernels of csrc/generic.hip (the fused path is relu, no norm)."""
@@ -738,7 +784,7 @@ class DynEdge(GNN):
             "globals": gv, "globals_after": self._add_global_variables_after_pooling,
             "features_subset": self._features_subset, "k": self._nb_neighbours, "strict": self._knn_strict,
             "pools": None if self._skip_readout else self._global_pooling_schemes,
-            "want_trace": return_trace, "wbuf": self._weight_buffers(),
+            "want_trace": return_trace, "wbuf": self._weight_buffers(), "side_stream": self._side_stream(x.device, int(x.shape[0])),
         }
         if self._is_generic():
             cfg["act"] = "gelu" if isinstance(self._activation, torch.nn.GELU) else "relu"

@@ -259,3 +259,28 @@ def test_queso_style_model_and_predict_as_dataframe(oracle):
     assert len(dfp) == sum(int(b.n_pulses.sum()) for b in bs) and list(dfp.columns) == ["target_pred", "event_no"]
     assert bool(((dfp["target_pred"] > 0) & (dfp["target_pred"] < 1)).all())
     assert list(dfp["event_no"][:int(bs[0].n_pulses[0])]) == [100.0] * int(bs[0].n_pulses[0]) and dfp["event_no"][n0] == 200
+
+
+def test_side_stream_overlap_is_bitwise_identical():
+    """``set_backend(overlap=True)``: graph building on a second HIP stream (k-NN beside the P|Q GEMM, reverse
+    adjacency beside the edge kernel) must not change a single bit of the outputs or the gradients."""
+    import graphnet_amd as g
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    b = synthetic_icecube86_batch(48, seed=5).to(DEV)
+    res = []
+    for overlap in (False, True, True):
+        torch.manual_seed(0)
+        m = g.DynEdge(7, global_pooling_schemes=["min", "max", "mean", "sum"]).to(DEV)
+        m.set_backend(dtype="bf16", overlap=overlap)
+        outs = []
+        for _ in range(3):                         # several steps: buffers are recycled across streams
+            m.zero_grad(set_to_none=True)
+            y = m(b)
+            y.square().sum().backward()
+            outs.append((y.detach().clone(), [p.grad.clone() for p in m.parameters()]))
+        torch.cuda.synchronize()
+        res.append(outs)
+    for other in res[1:]:
+        for (y0, g0), (y1, g1) in zip(res[0], other):
+            assert torch.equal(y0, y1)
+            assert all(torch.equal(a, c) for a, c in zip(g0, g1))
