@@ -156,6 +156,49 @@ class GraphDefinition(Model):
         return graph
 
 
+def _batch_from_raw(self: "GraphDefinition", events: "List[np.ndarray]", input_feature_names: "List[str]",
+                    truth: "Optional[Dict[str, Any]]" = None, device: str = "cuda") -> "Batch":
+    """Device-side replacement of the per-event loader path (``data/dataset/dataset.py:591-652`` +
+    ``data/dataloader.py:12-18``): raw pulse arrays of many events -> ONE flat ``[N, F]`` buffer + ``ptr`` -> one
+    host-to-device copy -> the detector's standardisation as one kernel over the whole batch
+    (``gn_standardize``, bit-identical to the per-event host expressions) -> ``Batch`` without edges (the backbone
+    builds the layer-1 k-NN on device, ``gn_knn_graph``).  Events with <= 1 pulse are dropped, as ``collate_fn``
+    does.  ``truth``: name -> per-event sequence (filtered alongside)."""
+    from .data import Batch
+    keep = [i for i, e in enumerate(events) if len(e) > 1]
+    sizes = np.asarray([len(events[i]) for i in keep], dtype=np.int64)
+    ptr = np.zeros(len(keep) + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum(sizes)
+    flat = torch.empty((int(ptr[-1]), len(input_feature_names)), dtype=self.dtype,
+                       pin_memory=torch.cuda.is_available() and device != "cpu")
+    flat_np = flat.numpy()
+    for j, i in enumerate(keep):
+        ev = np.asarray(events[i])
+        self._validate_input(ev, input_feature_names)
+        flat_np[ptr[j]:ptr[j + 1]] = self._perturb_input(ev.copy() if self._perturbation_dict else ev)
+    x = flat.to(device, non_blocking=True)
+    x = self._detector(x, input_feature_names)
+    if self._sort_by is not None:
+        raise NotImplementedError("graphnet_amd: sort_by is a per-event host option; use the per-event path")
+    b = Batch(x=x)
+    ptr_t = torch.from_numpy(ptr)
+    b.ptr = ptr_t.to(device)
+    n_pulses = torch.from_numpy(sizes).to(torch.int32)
+    b.n_pulses = n_pulses.to(device)
+    b.batch = torch.repeat_interleave(torch.arange(len(keep), dtype=torch.int64), torch.from_numpy(sizes)).to(device)
+    ed = self._edge_definition
+    if ed is not None and hasattr(ed, "_nb_nearest_neighbours"):
+        b.knn_k = int(ed._nb_nearest_neighbours)
+        b.knn_columns = list(ed._columns)
+    for k, vals in (truth or {}).items():
+        b[k] = torch.as_tensor(np.asarray([vals[i] for i in keep])).to(device)
+    b["graph_definition"] = self.__class__.__name__
+    return b
+
+
+GraphDefinition.batch_from_raw = _batch_from_raw
+
+
 class KNNGraph(GraphDefinition):
     """Edges drawn to the k nearest neighbours (``graphs/graphs.py:13-58``)."""
 

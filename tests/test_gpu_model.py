@@ -284,3 +284,30 @@ def test_side_stream_overlap_is_bitwise_identical():
         for (y0, g0), (y1, g1) in zip(res[0], other):
             assert torch.equal(y0, y1)
             assert all(torch.equal(a, c) for a, c in zip(g0, g1))
+
+
+def test_flat_buffer_device_batch_equals_per_event_loader_path():
+    """Raw pulses -> one flat buffer -> one H2D copy -> standardisation + layer-1 k-NN on device
+    (``GraphDefinition.batch_from_raw``) gives bit for bit the batch, and the model output, of the per-event host
+    path (``GraphDefinition.forward`` per event, ``collate_fn``, ``.to(device)``)."""
+    import graphnet_amd as g
+    from graphnet_amd.synthetic import synthetic_icecube86_raw, FEATURES_ICECUBE86
+    raw, ptr, energy = synthetic_icecube86_raw(12, seed=21)
+    events = [raw[ptr[i]:ptr[i + 1]].astype(np.float64) for i in range(12)]
+    gd = g.KNNGraph(g.IceCube86(), input_feature_names=FEATURES_ICECUBE86)
+    host = g.collate_fn([gd(e.copy(), FEATURES_ICECUBE86, truth_dicts=[{"energy": float(v)}])
+                         for e, v in zip(events, energy)]).to(DEV)
+    dev = gd.batch_from_raw(events, FEATURES_ICECUBE86, truth={"energy": list(energy)}, device=DEV)
+    assert dev.x.is_cuda
+    exact = [0, 1, 2, 3, 5, 6]                       # add / sub / mul / div programs: bit for bit the host result
+    assert torch.equal(dev.x[:, exact], host.x[:, exact])
+    # charge = log10(q): the device's log10f and the host libm's may differ in the last bit
+    assert torch.allclose(dev.x[:, 4], host.x[:, 4], rtol=3e-7, atol=1e-7)
+    assert torch.equal(dev.ptr, host.ptr) and torch.equal(dev.batch, host.batch)
+    torch.manual_seed(2)
+    m = g.DynEdge(7, global_pooling_schemes=["min", "max", "mean", "sum"]).to(DEV)
+    m.set_backend(dtype="fp32")
+    yd, td = m(dev, return_trace=True)
+    yh, th = m(host, return_trace=True)
+    assert torch.equal(td["graphs"][0].nbr, th["graphs"][0].nbr)        # same layer-1 graph (coordinates are exact)
+    assert rel_err(yd, yh.detach()) < 1e-5

@@ -370,3 +370,22 @@ def test_dropout_keep_rule_replica_properties():
     assert abs(k1[:, ::2].mean() - k1[:, 1::2].mean()) < 5e-3 and abs(k1[::2].mean() - k1[1::2].mean()) < 5e-3
     with pytest.raises(ValueError):
         ops.drop_thresh(1.0)
+
+
+def test_flat_buffer_batch_equals_per_event_path():
+    """``GraphDefinition.batch_from_raw`` (one flat buffer + ptr) against the per-event loader path
+    (``GraphDefinition.forward`` per event + ``collate_fn``): same rows, same CSR arrays, same truth columns, the
+    single-pulse event dropped.  (CPU here; the device path is checked bit for bit in tests/test_gpu_model.py.)"""
+    raw, ptr, energy = synthetic_icecube86_raw(5, seed=3)
+    events = [raw[ptr[i]:ptr[i + 1]].astype(np.float64) for i in range(5)]
+    events.insert(2, events[0][:1])                               # a one-pulse event
+    en = list(energy[:2]) + [7.0] + list(energy[2:])
+    gd = g.KNNGraph(g.IceCube86(), input_feature_names=FEATURES_ICECUBE86)
+    per_event = g.collate_fn([gd(e.copy(), FEATURES_ICECUBE86, truth_dicts=[{"energy": float(v)}])
+                              for e, v in zip(events, en)])
+    flat = gd.batch_from_raw(events, FEATURES_ICECUBE86, truth={"energy": en}, device="cpu")
+    assert torch.equal(flat.x, per_event.x)
+    assert torch.equal(flat.ptr, per_event.ptr) and torch.equal(flat.batch, per_event.batch)
+    assert torch.equal(flat.n_pulses, per_event.n_pulses)
+    assert torch.allclose(flat.energy.float(), per_event.energy.float())
+    assert flat.num_graphs == 5 and flat.knn_k == 8 and flat.knn_columns == [0, 1, 2]
