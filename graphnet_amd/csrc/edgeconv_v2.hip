@@ -305,6 +305,13 @@ __host__ __device__ constexpr int tr_pitch(int row_bytes) {
     return row_bytes + ((64 - row_bytes % 256) + 256) % 256;
 }
 
+// pitch >= row_bytes, multiple of 8 bytes, (pitch / 4) mod 32 == 18: see edge_bwd_v2_kernel
+__host__ __device__ constexpr int stage_pitch(int row_bytes) {
+    int p = (row_bytes + 7) / 8 * 8;
+    while ((p / 4) % 32 != 18) p += 8;
+    return p;
+}
+
 // The k1 (= H1p) range is split over HALVES workgroup populations so that the stationary
 // accumulator (32 x NBH*32 fp32 per wave) fits the 256-VGPR budget of 2 waves/SIMD: workgroup b
 // handles k1 blocks [kb0, kb0+nblk) (kb0 = (b % HALVES) * NBH) of the tile range b / HALVES, gathers
@@ -497,7 +504,14 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
     constexpr int K = NB1 * 32;                    // output width (H1p)
     constexpr int K2 = 256, KS2 = K2 / 16;         // contraction (H2)
     constexpr int DP = K2 * 2 + 16;                // dm tile pitch (b128 reads)
-    constexpr int SP = tr_pitch(K * 2);            // dpre staging pitch (ds_read_b64_tr_b16 conflict-free)
+    // dpre staging pitch.  The tile is WRITTEN column-wise (swapped operands: the 16 lanes of a ds_write_b64
+    // group are 16 consecutive rows at one column, banks (a/4) mod 32) and read back transposed
+    // (ds_read_b64_tr_b16: 4 consecutive rows per 32-lane group, banks mod 64).  The transposed-read pitch
+    // (== 16 dwords mod 64) puts all 16 rows of a write group on TWO bank pairs: 8-way conflicts, 209M
+    // SQ_LDS_BANK_CONFLICT cycles per launch.  A pitch of 18 dwords mod 32 spreads the 16 rows of a write group
+    // over all 32 banks (conflict-free) and leaves transposed reads that overlap in 2 banks only; rows are then
+    // 8-byte aligned, so the cooperative row reads below are ds_read_b64 pairs instead of ds_read_b128.
+    constexpr int SP = stage_pitch(K * 2);
     constexpr int HBW = (V2_ROWS * NB1 + NT - 1) / NT;   // hbits words per thread
     __shared__ __attribute__((aligned(16))) unsigned char Ds[2][V2_ROWS * DP];
     __shared__ __attribute__((aligned(16))) unsigned int Hb[2][V2_ROWS * NB1];
@@ -686,8 +700,12 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
                 const unsigned char* sp = &Stage[srow * SP + sc0 * 16];
                 unsigned char* gp = reinterpret_cast<unsigned char*>(dpre + rowg * K) + sc0 * 16;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<u32x4*>(gp + i * NB1 * 16) = *reinterpret_cast<const u32x4*>(sp + i * NB1 * 16);
+                for (int i = 0; i < 4; ++i) {
+                    typedef unsigned int u32x2_s __attribute__((ext_vector_type(2)));
+                    const u32x2_s lo = *reinterpret_cast<const u32x2_s*>(sp + i * NB1 * 16);
+                    const u32x2_s hi = *reinterpret_cast<const u32x2_s*>(sp + i * NB1 * 16 + 8);
+                    *reinterpret_cast<u32x4*>(gp + i * NB1 * 16) = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+                }
             }
         }
         __syncthreads();                                  // Stage may be overwritten by the next tile
