@@ -684,19 +684,18 @@ class DynEdge(GNN):
         self._knn_strict = {"compat": False, "strict": True}[knn_mode]
         if graph_columns is not None:
             self._graph_columns = list(graph_columns)
-        if overlap is not None:     # graph building on a second HIP stream beside the GEMM / edge kernels (default on)
+        if overlap is not None:     # graph building on a second HIP stream beside the GEMM / edge kernels (default off)
             self._overlap = bool(overlap)
         return self
 
     def _side_stream(self, device, n_pulses: int) -> Optional["torch.cuda.Stream"]:
-        """Second HIP stream for graph building (``set_backend(overlap=...)``, env ``GN_NO_OVERLAP=1`` disables);
-        never during hipGraph capture.  Default: on from 2^18 pulses per batch - measured +1.1 % at 623k pulses
-        (B = 4096), -1.8 % at 158k (B = 1024: the extra events and the shared vector ALU cost more than the overlap
-        returns)."""
-        overlap = getattr(self, "_overlap", None)
-        if overlap is None:
-            overlap = n_pulses >= (1 << 18)
-        if not overlap or os.environ.get("GN_NO_OVERLAP") == "1" or torch.cuda.is_current_stream_capturing():
+        """Second HIP stream for graph building: opt-in (``set_backend(overlap=True)``), never during hipGraph
+        capture.  Off by default: the persistent edge kernels occupy every CU for their whole run, and whether the
+        side stream's small kernels (scans of the reverse-adjacency build) get wave slots beside them is up to the
+        hardware dispatcher - measured from +1 % (26.3 -> 26.0 ms at B = 4096) to -40 % (36.8 ms: every scan
+        launch waited ~0.86 ms behind an edge kernel and the join stalled the main stream)."""
+        if not getattr(self, "_overlap", False) or os.environ.get("GN_NO_OVERLAP") == "1" or \
+                torch.cuda.is_current_stream_capturing():
             return None
         st = self.__dict__.get("_side")
         if st is None:
