@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphnet_amd.so")

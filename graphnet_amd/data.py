@@ -8,7 +8,7 @@ those attributes — including a real PyG ``Batch`` — is accepted by the backb
 """
 from __future__ import annotations
 
-from typing import Any, Dict, Iterator, List, Optional
+from typing import Any, Iterator, List, Optional
 
 import torch
 from torch import Tensor

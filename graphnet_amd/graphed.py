@@ -21,7 +21,7 @@ state created *inside* the capture would be re-initialised by every replay.
 """
 from __future__ import annotations
 
-from typing import Any, Callable, Dict, Optional, Tuple
+from typing import Any, Dict, Optional, Tuple
 
 import torch
 import torch.distributed as dist

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does a producer->consumer pair run faster when the intermediate buffer is small enough to stay in the 256 MB
 Infinity Cache?  write (fill) + read (sum) of a buffer of S MB, repeated so that the total bytes are constant."""
-import torch, time
+import torch
 dev = "cuda"
 total = 8 << 30
 for mb in (32, 64, 128, 192, 256, 384, 512, 1024, 4096):
