@@ -191,3 +191,49 @@ def test_dropout_kernel_statistics_and_replica():
     ops.dropout(xc, 7, th, out=xc)
     assert torch.equal(xc, yb)
     assert not torch.equal(ops.dropout(x, 1, th), y)
+
+
+def test_ragged_attention_edge_cases():
+    """Empty events between non-empty ones, a batch of one single-pulse event, and an empty batch."""
+    from graphnet_amd import ops
+    torch.manual_seed(4)
+    H, dh = 4, 32
+    d = H * dh
+    for ptr in ([0, 0, 5, 5, 5, 70, 70], [0, 1], [0, 0]):
+        N = ptr[-1]
+        ptr_d = torch.tensor(ptr, dtype=torch.int32, device=DEV)
+        plan = ops.knn_plan(ptr_d, N)
+        for dtype in (torch.float32, torch.bfloat16):
+            qkv = (torch.randn(N, 3 * d) * 1.3).to(dtype)
+            out, lse2 = ops.attention_fwd(qkv.to(DEV), H, ptr_d, plan)
+            assert out.shape == (N, d)
+            if N == 0:
+                continue
+            want = _ragged_attention_reference(qkv.double(), ptr, H)
+            assert rel_err(out, want) < (1e-5 if dtype == torch.float32 else 2e-2)
+            dq = ops.attention_bwd(qkv.to(DEV), H, ptr_d, plan, out, lse2, torch.ones_like(out))
+            assert torch.isfinite(dq.float()).all()
+            if N == 1:      # a single key: softmax = 1, output = V, dQ = dK = 0, dV = dO
+                assert rel_err(out, qkv[:, 2 * d:].double()) < 1e-6
+                assert float(dq[:, :2 * d].float().abs().max()) == 0.0
+                assert torch.allclose(dq[:, 2 * d:].float().cpu(), torch.ones(1, d))
+
+
+def test_batchnorm_rows_edge_cases():
+    """gn_bn_*: no valid row at all (statistics of an empty set: mean 0, rstd 1/sqrt(eps), outputs 0) and a single
+    valid row (biased variance 0)."""
+    from graphnet_amd import ops
+    R, C = 70, 32
+    z = torch.randn(R, C, device=DEV)
+    gam, bet = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    for nvalid in (0, 1):
+        valid = torch.full((R,), -1, dtype=torch.int32, device=DEV)
+        valid[:nvalid] = 3
+        nv = torch.tensor([nvalid], dtype=torch.int32, device=DEV)
+        mean, rstd, varu = ops.bn_stats(z, C, valid, nv, 1e-5)
+        a = ops.bn_act_fwd(z, C, valid, mean, rstd, gam, bet, "relu")
+        assert torch.isfinite(a).all() and float(a[nvalid:].abs().max()) == 0.0
+        if nvalid == 1:
+            assert torch.allclose(mean, z[0], atol=1e-6) and torch.allclose(a[0], torch.relu(bet), atol=1e-3)
+        dz, dg, db = ops.bn_act_bwd(torch.ones_like(z), z, C, valid, mean, rstd, gam, bet, "relu", nv)
+        assert torch.isfinite(dz).all() and torch.isfinite(dg).all() and torch.isfinite(db).all()
