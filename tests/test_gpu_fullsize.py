@@ -1,0 +1,138 @@
+"""GPU tests at the sizes of BASELINE.json / bench.py (B = 1024 and 4096 events per batch), where the CPU oracle
+cannot run the whole batch in reasonable time: size-independent properties of the domain (sortedness of the k-NN
+lists, event locality, determinism, independence of the events of a batch, permutation equivariance) plus oracle
+parity on a random subset of the events."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _d2(x, i, j):
+    """fp32 squared distance, accumulated left to right as the kernel and the oracle do: ((dx^2 + dy^2) + dz^2)."""
+    dx = x[j, 0] - x[i, 0]; dy = x[j, 1] - x[i, 1]; dz = x[j, 2] - x[i, 2]
+    return (dx * dx + dy * dy) + dz * dz
+
+
+@pytest.mark.parametrize("n_events", [1024, 4096])
+def test_knn_properties_at_bench_size(oracle, n_events):
+    from graphnet_amd import ops
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    b = synthetic_icecube86_batch(n_events, seed=20241016).to(DEV)
+    x = b.x[:, :3].contiguous()
+    N, k = int(x.shape[0]), 8
+    ptr32, batch32 = b.ptr.to(torch.int32), b.batch.to(torch.int32)
+    t1 = ops.knn_graph(b.x, [0, 1, 2], batch32, ptr32, k)
+    t2 = ops.knn_graph(b.x, [0, 1, 2], batch32, ptr32, k)
+    assert torch.equal(t1.nbr, t2.nbr) and torch.equal(t1.ovf, t2.ovf)                  # deterministic
+    nbr = t1.nbr.long()
+    valid = nbr >= 0
+    centre = torch.arange(N, device=DEV)[:, None].expand(N, k)
+    assert bool((nbr[valid] != centre[valid]).all())                                      # no self loops
+    assert bool((b.batch[nbr[valid]] == b.batch[centre[valid]]).all())                    # never crosses events
+    n_of = b.n_pulses.long()[b.batch]                                                     # event size per pulse
+    deg = valid.sum(1)
+    assert bool((deg == torch.clamp(n_of - 1, max=k)).all())                              # degree = min(k, n - 1)
+    # lists are sorted by (d2, j): d2 non-decreasing, indices ascending within equal d2
+    jj = torch.where(valid, nbr, centre)
+    d2 = _d2(x, centre.reshape(-1), jj.reshape(-1)).reshape(N, k)
+    d2 = torch.where(valid, d2, torch.full_like(d2, float("inf")))
+    assert bool((d2[:, 1:] >= d2[:, :-1]).all())
+    tie = (d2[:, 1:] == d2[:, :-1]) & valid[:, 1:]
+    assert bool((nbr[:, 1:][tie] > nbr[:, :-1][tie]).all())
+    # nothing closer was left out: every other pulse of the event is at least as far as the k-th neighbour -
+    # checked exhaustively (bit-exact against the oracle) on 40 random events
+    rng = np.random.default_rng(5)
+    ptr = b.ptr.cpu().numpy()
+    xc = b.x.cpu()
+    for e in rng.choice(n_events, 40, replace=False):
+        lo, hi = int(ptr[e]), int(ptr[e + 1])
+        sub = oracle.knn_table(xc[lo:hi], k, torch.tensor([0, hi - lo]), [0, 1, 2], "compat")[0]
+        want = torch.where(sub >= 0, sub + lo, sub)
+        assert torch.equal(t1.nbr[lo:hi].cpu(), want[:, :k].to(torch.int32)), int(e)
+        assert torch.equal(t1.ovf[lo:hi].cpu(), want[:, k].to(torch.int32)), int(e)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_events_of_a_batch_are_independent_at_bench_size(dtype):
+    """B = 1024: the latent vector of an event does not depend on which other events share its batch (bit for bit:
+    every kernel treats rows / events independently and every reduction has a fixed order), the step is
+    deterministic, and permuting the events permutes the outputs."""
+    import graphnet_amd as g
+    from graphnet_amd.data import Batch
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    full = synthetic_icecube86_batch(1024, seed=20241016)
+
+    def sub_batch(ids):
+        ptr = full.ptr.numpy()
+        rows = np.concatenate([np.arange(ptr[i], ptr[i + 1]) for i in ids])
+        n = torch.tensor([ptr[i + 1] - ptr[i] for i in ids], dtype=torch.int64)
+        sb = Batch(x=full.x[rows])
+        sb.ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(n, 0)])
+        sb.batch = torch.repeat_interleave(torch.arange(len(ids)), n)
+        sb.n_pulses = n.to(torch.int32)
+        sb.energy = full.energy[list(ids)]
+        return sb
+
+    torch.manual_seed(0)
+    m = g.DynEdge(7, global_pooling_schemes=["min", "max", "mean", "sum"]).to(DEV)
+    m.set_backend(dtype=dtype)
+    with torch.no_grad():
+        y = m(full.to(DEV))
+        y_again = m(full)
+        assert torch.equal(y, y_again)
+        full.to("cpu")
+        first = list(range(64))
+        y64 = m(sub_batch(first).to(DEV))
+        assert torch.equal(y64, y[:64])
+        perm = np.random.default_rng(1).permutation(1024)[:200]
+        yp = m(sub_batch(list(perm)).to(DEV))
+        assert torch.equal(yp, y[torch.from_numpy(perm).to(DEV)])
+    # training step: loss and every gradient reproduce bit for bit
+    grads = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        out = m(full.to(DEV))
+        out.square().mean().backward()
+        grads.append([p.grad.clone() for p in m.parameters()])
+    assert all(torch.equal(a, c) for a, c in zip(*grads))
+    assert all(torch.isfinite(a).all() for a in grads[0])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_ragged_attention_properties_at_config4_size(dtype, tol):
+    """BASELINE configs[3] scale (64 events of 50-3000 pulses, 8 heads x 32): softmax rows sum to one (constant V
+    comes back unchanged), the output is linear in V, events do not see each other (changing one event's K / V
+    leaves every other event's output bit-identical), and the run is deterministic."""
+    from graphnet_amd import ops
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    b = synthetic_icecube86_batch(64, seed=5, count_range=(50, 3000))
+    ptr_d = b.ptr.to(torch.int32).to(DEV)
+    N, H, d = int(b.x.shape[0]), 8, 256
+    plan = ops.knn_plan(ptr_d, N)
+    gen = torch.Generator().manual_seed(3)
+    q = torch.randn(N, d, generator=gen)
+    kk = torch.randn(N, d, generator=gen)
+    v1 = torch.randn(N, d, generator=gen)
+    v2 = torch.randn(N, d, generator=gen)
+
+    def att(v, k=kk):
+        return ops.attention_fwd(torch.cat([q, k, v], 1).to(dtype).to(DEV), H, ptr_d, plan)[0].float()
+
+    const = torch.full((N, d), 0.75)
+    assert float((att(const) - 0.75).abs().max()) < (1e-5 if dtype == torch.float32 else 1e-2)
+    o1, o2 = att(v1), att(v2)
+    o12 = att(2.0 * v1 - 0.5 * v2)
+    err = (o12 - (2.0 * o1 - 0.5 * o2)).abs().max() / o12.abs().max()
+    assert float(err) < tol
+    assert torch.equal(att(v1), o1)
+    lo, hi = int(b.ptr[10]), int(b.ptr[11])
+    k_mod, v_mod = kk.clone(), v1.clone()
+    k_mod[lo:hi] += 1.0
+    v_mod[lo:hi] -= 2.0
+    o_mod = att(v_mod, k_mod)
+    keep = torch.ones(N, dtype=torch.bool)
+    keep[lo:hi] = False
+    assert torch.equal(o_mod[keep.to(DEV)], o1[keep.to(DEV)]) and not torch.equal(o_mod[lo:hi], o1[lo:hi])
