@@ -152,3 +152,14 @@ def test_tito_oracle_state_dict_keys_match_the_reference_layout():
         assert k in keys, k
     assert m.state_dict()["_conv_layers.0.nn.0.weight"].shape == (32, 21)
     assert m.state_dict()["_readout.0.weight"].shape == (32, 32 + 12)
+
+
+def test_c_oracle_under_address_and_ub_sanitizers():
+    """SURVEY §5 (sanitizers): the C restatement of the k-NN is built with -fsanitize=address,undefined together with
+    a self-test over ragged / degenerate events (``oracle/knn_selftest.c``) and must run clean."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    res = subprocess.run(["make", "-C", here, "selftest"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout[-2000:]
+    assert "knn_selftest: ok" in res.stdout
