@@ -59,6 +59,7 @@ SIGNATURES = {
     "gn_pack_weights": (I32, [P, I32, P]),
     "gn_segment_pool_fwd": (I32, [P, I64, I32, P, I32, P, I32, P, P, P, P]),
     "gn_segment_pool_bwd": (I32, [P, I32, P, P, I32, P, I32, P, P, P, I64, P, I64, I32, P]),
+    "gn_attention_plan": (I32, [P, I32, P, I32, P]),
     "gn_attention_fwd": (I32, [I32, P, I64, I32, I32, P, P, I32, I32, P, I64, P, U32, U32, P]),
     "gn_attention_bwd": (I32, [I32, P, I64, I32, I32, P, P, I32, I32, P, I64, P, I64, P, P, P, I64, U32, U32, P]),
     "gn_bn_blocks": (I64, [I64]),

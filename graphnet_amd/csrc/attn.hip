@@ -24,6 +24,32 @@ __device__ __forceinline__ int attn_event_of_tile(const int* __restrict__ tile_p
     return lo;
 }
 
+// Attention plan: plan[0..B] = first tile of every event IN PLAN ORDER (exclusive scan of ceil(n/64)),
+// plan[B+1 .. 2B] = the event at each position.  sorted: events in descending size (ties by index) - the longest
+// waves are dispatched first, so the launch does not end on the tail of the largest event; else identity order.
+// One workgroup; rank by counting is O(B^2 / 1024) per thread, the scan is a serial pass: B <= 8192 sorted.
+__global__ __launch_bounds__(1024) void attn_plan_kernel(const int* __restrict__ ptr, int B, int* __restrict__ plan, int sorted) {
+    for (int e = threadIdx.x; e < B; e += 1024) {
+        const int n = max(ptr[e + 1] - ptr[e], 0);
+        int rank = e;
+        if (sorted) {
+            rank = 0;
+            for (int o = 0; o < B; ++o) {
+                const int m = max(ptr[o + 1] - ptr[o], 0);
+                rank += (m > n || (m == n && o < e)) ? 1 : 0;
+            }
+        }
+        plan[B + 1 + rank] = e;
+        plan[rank] = (n + ATT_TILE - 1) / ATT_TILE;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int r = 0; r < B; ++r) { const int t = plan[r]; plan[r] = run; run += t; }
+        plan[B] = run;
+    }
+}
+
 // stage rows [r0, r0+64) (clamped to r_last) x DH floats of column block `col0` into LDS [64][DH]
 template <int DH>
 __device__ __forceinline__ void attn_stage(float* __restrict__ dst, const float* __restrict__ src, long long ld,
@@ -47,9 +73,10 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(
     __shared__ float Vs[ATT_TILE * DH];
     const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     if (tile >= tile_ptr[B]) return;
-    const int e = attn_event_of_tile(tile_ptr, B, tile);
+    const int es = attn_event_of_tile(tile_ptr, B, tile);          // position in the plan's (size-sorted) event order
+    const int e = tile_ptr[B + 1 + es];
     const int kbeg = ptr[e], kend = ptr[e + 1];
-    const int q0 = kbeg + (tile - tile_ptr[e]) * ATT_TILE;
+    const int q0 = kbeg + (tile - tile_ptr[es]) * ATT_TILE;
     const int E = H * DH;
     const int qi = q0 + lane;
     const bool valid = qi < kend;
@@ -127,9 +154,10 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(
     __shared__ float Vs[ATT_TILE * DH];
     const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     if (tile >= tile_ptr[B]) return;
-    const int e = attn_event_of_tile(tile_ptr, B, tile);
+    const int es = attn_event_of_tile(tile_ptr, B, tile);          // position in the plan's (size-sorted) event order
+    const int e = tile_ptr[B + 1 + es];
     const int kbeg = ptr[e], kend = ptr[e + 1];
-    const int q0 = kbeg + (tile - tile_ptr[e]) * ATT_TILE;
+    const int q0 = kbeg + (tile - tile_ptr[es]) * ATT_TILE;
     const int E = H * DH;
     const int qi = q0 + lane;
     const bool valid = qi < kend;
@@ -204,9 +232,10 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(
     __shared__ float Ds[ATT_TILE];
     const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     if (tile >= tile_ptr[B]) return;
-    const int e = attn_event_of_tile(tile_ptr, B, tile);
+    const int es = attn_event_of_tile(tile_ptr, B, tile);          // position in the plan's (size-sorted) event order
+    const int e = tile_ptr[B + 1 + es];
     const int kbeg = ptr[e], kend = ptr[e + 1];
-    const int k0 = kbeg + (tile - tile_ptr[e]) * ATT_TILE;
+    const int k0 = kbeg + (tile - tile_ptr[es]) * ATT_TILE;
     const int E = H * DH;
     const int kj = k0 + lane;
     const bool valid = kj < kend;
@@ -328,9 +357,10 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(
     __shared__ __attribute__((aligned(16))) unsigned char Vs[32 * VP];
     const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     if (tile >= tile_ptr[B]) return;
-    const int e = attn_event_of_tile(tile_ptr, B, tile);
+    const int es = attn_event_of_tile(tile_ptr, B, tile);          // position in the plan's (size-sorted) event order
+    const int e = tile_ptr[B + 1 + es];
     const int kbeg = ptr[e], kend = ptr[e + 1];
-    const int q0 = kbeg + (tile - tile_ptr[e]) * ATT_TILE;
+    const int q0 = kbeg + (tile - tile_ptr[es]) * ATT_TILE;
     const int E = H * DH, c = lane & 31, h = lane >> 5;
     bf16x8 qf[2][KS];
 #pragma unroll
@@ -435,9 +465,10 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_mfma_kernel(
     __shared__ __attribute__((aligned(16))) unsigned char Ks[32 * VP];
     const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     if (tile >= tile_ptr[B]) return;
-    const int e = attn_event_of_tile(tile_ptr, B, tile);
+    const int es = attn_event_of_tile(tile_ptr, B, tile);          // position in the plan's (size-sorted) event order
+    const int e = tile_ptr[B + 1 + es];
     const int kbeg = ptr[e], kend = ptr[e + 1];
-    const int q0 = kbeg + (tile - tile_ptr[e]) * ATT_TILE;
+    const int q0 = kbeg + (tile - tile_ptr[es]) * ATT_TILE;
     const int E = H * DH, c = lane & 31, h = lane >> 5;
     const float scale2 = scale * LOG2E;
     bf16x8 qf[2][KS], gf[2][KS];
@@ -540,9 +571,10 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_mfma_kernel(
     __shared__ __attribute__((aligned(16))) float Ds[32];
     const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     if (tile >= tile_ptr[B]) return;
-    const int e = attn_event_of_tile(tile_ptr, B, tile);
+    const int es = attn_event_of_tile(tile_ptr, B, tile);          // position in the plan's (size-sorted) event order
+    const int e = tile_ptr[B + 1 + es];
     const int kbeg = ptr[e], kend = ptr[e + 1];
-    const int k0 = kbeg + (tile - tile_ptr[e]) * ATT_TILE;
+    const int k0 = kbeg + (tile - tile_ptr[es]) * ATT_TILE;
     const int E = H * DH, c = lane & 31, h = lane >> 5;
     const float scale2 = scale * LOG2E;
     bf16x8 kf[2][KS], vf[2][KS];
@@ -659,6 +691,12 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_mfma_kernel(
 
 static bool attn_shape_ok(int DH, long long ld, long long ldo) {
     return (DH == 8 || DH == 16 || DH == 32 || DH == 64) && ld % 4 == 0 && ldo % 4 == 0;
+}
+
+hipError_t launch_attn_plan(const int* ptr, int B, int* plan, int sorted, hipStream_t st) {
+    if (B < 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_plan_kernel, dim3(1), dim3(1024), 0, st, ptr, B, plan, (sorted && B <= 8192) ? 1 : 0);
+    return hipGetLastError();
 }
 
 static Drop make_drop(unsigned seed, unsigned thresh) {

@@ -266,6 +266,11 @@ int gn_segment_pool_bwd(const float* gout, int32_t C, const int32_t* ptr, const 
 }
 
 
+int gn_attention_plan(const int32_t* ptr, int32_t B, int32_t* plan, int32_t sorted, void* stream) {
+    hipError_t r = gn::launch_attn_plan(ptr, B, plan, sorted, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_attention_plan", "B >= 0");
+    return fail(r, "gn_attention_plan");
+}
 int gn_attention_fwd(int32_t lowp, const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr,
                      const int32_t* tile_ptr, int32_t B, int32_t N, void* out, int64_t ldo, float* lse2, uint32_t drop_seed,
                      uint32_t drop_thresh, void* stream) {

@@ -87,7 +87,9 @@ hipError_t launch_bn_act_bwd(const float* g, long long ldg, const float* z, long
                              const int* valid, const float* mean, const float* rstd, const float* gamma, const float* beta,
                              const float* sums, const int* n_valid, int act, void* dz, long long lddz, int Cpad, int dz_lowp,
                              hipStream_t st);
-// attn.hip  (lowp: qkv / out / dout / dqkv are bf16 and the MFMA kernels run; else fp32 on the vector ALU)
+// attn.hip
+hipError_t launch_attn_plan(const int* ptr, int B, int* plan, int sorted, hipStream_t st);
+// (lowp: qkv / out / dout / dqkv are bf16 and the MFMA kernels run; else fp32 on the vector ALU)
 hipError_t launch_attn_fwd(int lowp, const void* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
                            int B, int N, void* out, long long ldo, float* lse2, unsigned seed, unsigned thresh,
                            hipStream_t st);

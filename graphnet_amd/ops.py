@@ -645,6 +645,15 @@ def segment_pool_bwd(gout: Tensor, C: int, ptr: Tensor, batch: Tensor, N: int, s
 
 
 # ------------------------------------------------------------------------------ ragged self attention (DynTrans)
+def attention_plan(ptr: Tensor, sort: bool = True) -> Tensor:
+    """Tile plan of the attention kernels (``gn_attention_plan``): int32 ``[2B+1]``, events in descending size."""
+    _need(ptr, torch.int32, "ptr")
+    B = int(ptr.shape[0]) - 1
+    plan = torch.empty(2 * B + 1, dtype=torch.int32, device=ptr.device)
+    _lib.check(_lib.lib().gn_attention_plan(_p(ptr), B, _p(plan), int(sort), _st()))
+    return plan
+
+
 def attention_lowp(mode: int, d_model: int, n_head: int) -> bool:
     """bf16 tensors + matrix-core kernels are available for head widths 32 and 64 in bf16 mode."""
     return mode == MODE_BF16 and d_model % n_head == 0 and d_model // n_head in (32, 64)
@@ -677,7 +686,7 @@ def dropout(x: Tensor, seed: int, thresh: int, res: Optional[Tensor] = None, out
 def attention_fwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, drop: Optional[Tuple[int, int]] = None):
     """``softmax(Q K^T / sqrt(dh)) V`` per head, every pulse attending to its own event (``gn_attention_fwd``).
     ``qkv`` ``[N, 3 d]`` (Q | K | V): fp32 -> exact-fp32 kernels, bf16 -> matrix-core kernels (dh 32 / 64);
-    ``plan`` from :func:`knn_plan`; ``drop=(seed, thresh)``: dropout on the attention probabilities.
+    ``plan`` from :func:`attention_plan`; ``drop=(seed, thresh)``: dropout on the attention probabilities.
     -> (out [N, d] in qkv's type, lse2 [N, H] fp32)."""
     if qkv.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("qkv must be fp32 or bf16")

@@ -353,7 +353,7 @@ class DynEdgeTITO(GNN):
             ei = _maybe(data, "edge_index")
             table = ops.table_from_edge_index(ei, N, self._nb_neighbours) if ei is not None else \
                 ops.knn_graph(x, self._graph_columns, batch32, ptr32, self._nb_neighbours, strict=self._knn_strict)
-        plan = ops.knn_plan(ptr32, N)
+        plan = ops.attention_plan(ptr32)
         gv = ops.graph_globals(x, ptr32, table, n_pulses) if self._use_global_features else None
         seed_log: List[List[int]] = []
         cfg = {"mode": self._compute_mode, "graph": table, "ptr": ptr32, "batch": batch32, "plan": plan,

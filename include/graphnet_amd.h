@@ -241,13 +241,16 @@ int gn_segment_pool_bwd(const float* gout, int32_t C, const int32_t* ptr, const 
 /* ---- ragged multi-head self attention (DynTrans, models/components/layers.py:166-197) ---- */
 /* Replaces to_dense_batch + torch.nn.TransformerEncoder's attention + x[mask]: every pulse attends to the
  * pulses of its own event (ptr), nothing is padded.  qkv[N, ld] = [Q | K | V], each H*DH wide (the in_proj
- * output); tile_ptr from gn_knn_plan; out[N, ldo] = softmax(Q K^T / sqrt(DH)) V per head, heads side by side;
+ * output); tile_ptr = the plan of gn_attention_plan (int32[2B+1]: first 64-row tile of every event in plan order,
+ * then the event at each position; sorted != 0: largest events first, so that the launch does not end on the tail
+ * of the longest event); out[N, ldo] = softmax(Q K^T / sqrt(DH)) V per head, heads side by side;
  * lse2[N, H] fp32 = log2 of the softmax denominators (saved for the backward).  gn_attention_bwd: dqkv[N, lddq] =
  * gradient w.r.t. qkv given dout; delta[N, H] fp32 is scratch.
  * lowp = 0: qkv / out / dout / dqkv are fp32, exact-fp32 kernels on the vector ALU, DH in {8, 16, 32, 64}.
  * lowp = 1: those four tensors are bf16, products on the matrix core (fp32 softmax statistics and accumulation),
  *           DH in {32, 64}.
  * drop_thresh != 0: dropout on the attention probabilities (see gn_dropout for the rule). */
+int gn_attention_plan(const int32_t* ptr, int32_t B, int32_t* plan, int32_t sorted, void* stream);
 int gn_attention_fwd(int32_t lowp, const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr,
                      const int32_t* tile_ptr, int32_t B, int32_t N, void* out, int64_t ldo, float* lse2, uint32_t drop_seed,
                      uint32_t drop_thresh, void* stream);

@@ -111,7 +111,7 @@ def test_ragged_attention_properties_at_config4_size(dtype, tol):
     b = synthetic_icecube86_batch(64, seed=5, count_range=(50, 3000))
     ptr_d = b.ptr.to(torch.int32).to(DEV)
     N, H, d = int(b.x.shape[0]), 8, 256
-    plan = ops.knn_plan(ptr_d, N)
+    plan = ops.attention_plan(ptr_d)
     gen = torch.Generator().manual_seed(3)
     q = torch.randn(N, d, generator=gen)
     kk = torch.randn(N, d, generator=gen)

@@ -66,7 +66,7 @@ def test_ragged_attention_forward_backward(H, dh, p_drop):
     w = torch.randn(N, d, dtype=torch.float64)
     (want * w).sum().backward()
     ptr_d = torch.tensor(ptr, dtype=torch.int32, device=DEV)
-    plan = ops.knn_plan(ptr_d, N)
+    plan = ops.attention_plan(ptr_d)
     x = qkv.detach().float().to(DEV)
     out, lse2 = ops.attention_fwd(x, H, ptr_d, plan, drop=drop)
     assert rel_err(out, want.detach()) < 1e-5          # fp32 flash accumulation against fp64
@@ -95,7 +95,7 @@ def test_ragged_attention_forward_backward(H, dh, p_drop):
 def test_ragged_attention_rejects_unsupported_head_width():
     from graphnet_amd import ops
     ptr_d = torch.tensor([0, 4], dtype=torch.int32, device=DEV)
-    plan = ops.knn_plan(ptr_d, 4)
+    plan = ops.attention_plan(ptr_d)
     with pytest.raises(RuntimeError, match="head width"):
         ops.attention_fwd(torch.zeros(4, 3 * 24, device=DEV), 2, ptr_d, plan)
 
@@ -202,7 +202,7 @@ def test_ragged_attention_edge_cases():
     for ptr in ([0, 0, 5, 5, 5, 70, 70], [0, 1], [0, 0]):
         N = ptr[-1]
         ptr_d = torch.tensor(ptr, dtype=torch.int32, device=DEV)
-        plan = ops.knn_plan(ptr_d, N)
+        plan = ops.attention_plan(ptr_d)
         for dtype in (torch.float32, torch.bfloat16):
             qkv = (torch.randn(N, 3 * d) * 1.3).to(dtype)
             out, lse2 = ops.attention_fwd(qkv.to(DEV), H, ptr_d, plan)
@@ -217,6 +217,28 @@ def test_ragged_attention_edge_cases():
                 assert rel_err(out, qkv[:, 2 * d:].double()) < 1e-6
                 assert float(dq[:, :2 * d].float().abs().max()) == 0.0
                 assert torch.allclose(dq[:, 2 * d:].float().cpu(), torch.ones(1, d))
+
+
+def test_attention_plan_orders_events_by_size_and_does_not_change_results():
+    from graphnet_amd import ops
+    sizes = [5, 300, 0, 64, 300, 1, 129]
+    ptr = [0]
+    for n in sizes:
+        ptr.append(ptr[-1] + n)
+    B = len(sizes)
+    ptr_d = torch.tensor(ptr, dtype=torch.int32, device=DEV)
+    plan = ops.attention_plan(ptr_d).cpu().tolist()
+    order = plan[B + 1:]
+    assert order == [1, 4, 6, 3, 0, 5, 2]                                   # descending size, ties by index
+    tiles = [(sizes[e] + 63) // 64 for e in order]
+    assert plan[:B + 1] == [sum(tiles[:i]) for i in range(B + 1)]
+    ident = ops.attention_plan(ptr_d, sort=False).cpu().tolist()
+    assert ident[B + 1:] == list(range(B))
+    torch.manual_seed(1)
+    qkv = torch.randn(ptr[-1], 3 * 128).to(torch.bfloat16).to(DEV)
+    a, la = ops.attention_fwd(qkv, 4, ptr_d, ops.attention_plan(ptr_d))
+    b_, lb = ops.attention_fwd(qkv, 4, ptr_d, ops.attention_plan(ptr_d, sort=False))
+    assert torch.equal(a, b_) and torch.equal(la, lb)
 
 
 def test_batchnorm_rows_edge_cases():
