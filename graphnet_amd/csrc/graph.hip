@@ -628,6 +628,104 @@ hipError_t launch_ovf_compact(const int* ovf, int N, int* flag_pos /*[N]*/, int*
     return hipGetLastError();
 }
 
+// ---- event-local build: graphs whose edges never leave an event (everything gn_knn_graph produces) ----
+// One workgroup per event does count, scan and fill with the in-degree counters in LDS (events of up to
+// REV_EV_CAP pulses; larger ones use the event's slice of a global scratch array, same code): 3 launches that read
+// the neighbour table twice instead of the global path's count / scan / fill / hub search over N atomics in HBM.
+// ovf[i] = source of centre i's (k+1)-th edge or -1; ovf_pos[i] = index of that overflow row (row id N*S + ovf_pos[i]).
+constexpr int REV_EV_CAP = 8192;
+__global__ __launch_bounds__(256) void rev_event_count(const int* __restrict__ nbr, const int* __restrict__ ovf,
+                                                      const int* __restrict__ ptr, int K, int* __restrict__ ev_edges,
+                                                      int* __restrict__ nhubs) {
+    __shared__ int red[4];
+    const int e = blockIdx.x, lo = ptr[e], hi = ptr[e + 1];
+    int c = 0;
+    for (long long t = (long long)lo * K + threadIdx.x; t < (long long)hi * K; t += 256) c += nbr[t] >= 0 ? 1 : 0;
+    if (ovf)
+        for (int i = lo + threadIdx.x; i < hi; i += 256) c += ovf[i] >= 0 ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ev_edges[e] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (e == 0) *nhubs = 0;
+    }
+}
+__global__ __launch_bounds__(256) void rev_event_build(const int* __restrict__ nbr, const int* __restrict__ ovf,
+                                                      const int* __restrict__ ovf_pos, const int* __restrict__ ptr,
+                                                      const int* __restrict__ ev_base, int B, int N, int K, int S,
+                                                      int* __restrict__ rev_ptr, int* __restrict__ rev_rows,
+                                                      int* __restrict__ scratch, int* __restrict__ hubs,
+                                                      int* __restrict__ nhubs) {
+    __shared__ int lds_cnt[REV_EV_CAP];
+    __shared__ int chunk_sum[256];
+    const int e = blockIdx.x, lo = ptr[e], hi = ptr[e + 1], n = hi - lo, tid = threadIdx.x;
+    const int base = ev_base[e];
+    if (e == B - 1 && tid == 0) rev_ptr[N] = ev_base[B];
+    if (n <= 0) return;
+    int* cnt = n <= REV_EV_CAP ? lds_cnt : scratch + lo;       // workgroup-uniform
+    for (int j = tid; j < n; j += 256) cnt[j] = 0;
+    __syncthreads();
+    for (long long t = (long long)lo * K + tid; t < (long long)hi * K; t += 256) {
+        const int j = nbr[t];
+        if (j >= 0) atomicAdd(&cnt[j - lo], 1);
+    }
+    if (ovf)
+        for (int i = lo + tid; i < hi; i += 256) { const int j = ovf[i]; if (j >= 0) atomicAdd(&cnt[j - lo], 1); }
+    __threadfence_block();
+    __syncthreads();
+    // exclusive scan of cnt[0..n): thread t owns the contiguous piece [t*per, (t+1)*per)
+    const int per = (n + 255) / 256;
+    const int j0 = min(tid * per, n), j1 = min(j0 + per, n);
+    int sum = 0;
+    for (int j = j0; j < j1; ++j) sum += cnt[j];
+    chunk_sum[tid] = sum;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int t = 0; t < 256; ++t) { const int v = chunk_sum[t]; chunk_sum[t] = run; run += v; } }
+    __syncthreads();
+    int run = chunk_sum[tid];
+    for (int j = j0; j < j1; ++j) {
+        const int d = cnt[j];
+        cnt[j] = run;                                            // becomes the fill cursor of source j
+        rev_ptr[lo + j] = base + run;
+        if (d > REV_SORT_MIN && d <= REV_SORT_CAP) hubs[atomicAdd(nhubs, 1)] = lo + j;
+        run += d;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (long long t = (long long)lo * K + tid; t < (long long)hi * K; t += 256) {
+        const int j = nbr[t];
+        if (j >= 0) {
+            const int i = (int)(t / K), sl = (int)(t % K);
+            rev_rows[base + atomicAdd(&cnt[j - lo], 1)] = i * S + sl;
+        }
+    }
+    if (ovf)
+        for (int i = lo + tid; i < hi; i += 256) {
+            const int j = ovf[i];
+            if (j >= 0) rev_rows[base + atomicAdd(&cnt[j - lo], 1)] = N * S + ovf_pos[i];
+        }
+}
+
+// ev: >= 2*(B+1) ints of workspace (edges per event, their exclusive scan); scratch: [N] ints (events above
+// REV_EV_CAP pulses); hubs: [N] ints, nhubs: [1] (the hub list for gn_edgeconv_dq_gather); tmp: scan workspace
+hipError_t launch_rev_build_events(const int* nbr, int N, int K, int S, const int* ovf, const int* ovf_pos, const int* ptr,
+                                   int B, int* rev_ptr, int* rev_rows, int* ev, int* scratch, int* hubs, int* nhubs,
+                                   int* tmp, hipStream_t st) {
+    if (N == 0 || B == 0) return hipSuccess;
+    if ((long long)N * S + N >= (1ll << 31)) return hipErrorInvalidValue;
+    int* ev_edges = ev;
+    int* ev_base = ev + (B + 1);
+    hipLaunchKernelGGL(rev_event_count, dim3(B), dim3(256), 0, st, nbr, ovf, ptr, K, ev_edges, nhubs);
+    hipError_t e = launch_scan(ev_edges, ev_base, B, tmp, ev_base + B, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rev_event_build, dim3(B), dim3(256), 0, st, nbr, ovf, ovf_pos, ptr, ev_base, B, N, K, S, rev_ptr,
+                       rev_rows, scratch, hubs, nhubs);
+    hipLaunchKernelGGL(rev_sort_kernel, dim3(N < 1024 ? N : 1024), dim3(256), 0, st, rev_ptr, hubs, nhubs, rev_rows);
+    return hipGetLastError();
+}
+
 hipError_t launch_rev_build(const int* nbr, int N, int K, int S, const int* ovf_src, const int* ovf_cnt,
                             int* rev_ptr /*[N+1]*/, int* cursor /*[N]*/, int* tmp, int* rev_rows, hipStream_t st) {
     if (N == 0) return hipSuccess;

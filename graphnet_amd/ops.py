@@ -125,6 +125,24 @@ class NeighbourTable:
             return
         L = _lib.lib()
         N, dev = self.N, self.nbr.device
+        ev_ptr = getattr(self, "event_ptr", None)
+        if ev_ptr is not None and (self.ovf is None or getattr(self, "ovf_pos", None) is not None):
+            # edges never leave an event (built by knn_graph): per-event build with LDS counters
+            B = int(ev_ptr.shape[0]) - 1
+            rev_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+            rev_rows = torch.empty(max(N * self.K + N, 1), dtype=torch.int32, device=dev)
+            ev = torch.empty(2 * (B + 1), dtype=torch.int32, device=dev)
+            scratch = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+            hubs = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+            tmp = torch.empty(int(L.gn_scan_tmp_ints(max(B, 1))) + 1, dtype=torch.int32, device=dev)
+            nhubs = tmp[-1:]
+            with _timed("rev_build"):
+                _lib.check(L.gn_rev_build_events(_p(self.nbr), N, self.K, _p(self.ovf), _p(getattr(self, "ovf_pos", None)),
+                                                 _p(ev_ptr), B, _p(rev_ptr), _p(rev_rows), _p(ev), _p(scratch), _p(hubs),
+                                                 _p(nhubs), _p(tmp), _st()))
+            self.rev_ptr, self.rev_rows = rev_ptr, rev_rows
+            self.rev_hubs, self.rev_nhubs = hubs, nhubs
+            return
         rev_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         cursor = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
         tmp = torch.empty(int(L.gn_scan_tmp_ints(N)), dtype=torch.int32, device=dev)
@@ -162,7 +180,9 @@ def _finish_table(nbr: Tensor, ovf: Optional[Tensor], K: int) -> NeighbourTable:
     os_ = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     _lib.check(L.gn_ovf_compact(_p(ovf), N, _p(work), _p(tmp), _p(oc), _p(os_), _p(cnt), _st()))
-    return NeighbourTable(nbr, ovf, oc, os_, cnt, K)
+    t = NeighbourTable(nbr, ovf, oc, os_, cnt, K)
+    t.ovf_pos = work            # exclusive scan of the overflow flags: index of every centre's overflow row
+    return t
 
 
 def knn_plan(ptr: Tensor, n_nodes: int) -> Tensor:
@@ -189,7 +209,9 @@ def knn_graph(x: Tensor, cols: Sequence[int], batch: Tensor, ptr: Tensor, k: int
     with _timed("knn_graph"):
         _lib.check(_lib.lib().gn_knn_graph(_p(x), ld, ctypes.cast(c, ctypes.c_void_p), len(cols), _p(ptr),
                                            _p(plan), int(ptr.shape[0]) - 1, N, k, 1 if strict else 0, _p(nbr), _p(ovf), _st()))
-    return _finish_table(nbr, None if strict else ovf[:N] if N else ovf, k)
+    table = _finish_table(nbr, None if strict else ovf[:N] if N else ovf, k)
+    table.event_ptr = ptr       # every edge stays inside its event: the reverse lists can be built event by event
+    return table
 
 
 def table_from_edge_index(edge_index: Tensor, N: int, K: int) -> NeighbourTable:

@@ -65,6 +65,14 @@ int gn_ovf_compact(const int32_t* ovf, int32_t N, int32_t* work_N, int32_t* tmp,
 int32_t gn_edge_slots(int32_t K);
 int gn_rev_build(const int32_t* nbr, int32_t N, int32_t K, const int32_t* ovf_src, const int32_t* ovf_cnt,
                  int32_t* rev_ptr, int32_t* cursor, int32_t* tmp, int32_t* rev_rows, void* stream);
+/* Same result for graphs whose edges never leave an event (what gn_knn_graph builds): one workgroup per event
+ * counts, scans and fills with the in-degree counters in LDS.  ovf: per-centre overflow source ([N], -1 = none; the
+ * array gn_knn_graph wrote) or NULL; ovf_pos[i]: index of centre i's overflow row (the exclusive scan gn_ovf_compact
+ * leaves in its `work` array); ev: 2*(B+1) ints and scratch: N ints of workspace; hubs [N] / nhubs [1]: the hub list
+ * for gn_edgeconv_dq_gather; tmp: gn_scan_tmp_ints(B) ints. */
+int gn_rev_build_events(const int32_t* nbr, int32_t N, int32_t K, const int32_t* ovf, const int32_t* ovf_pos,
+                        const int32_t* ptr, int32_t B, int32_t* rev_ptr, int32_t* rev_rows, int32_t* ev,
+                        int32_t* scratch, int32_t* hubs, int32_t* nhubs, int32_t* tmp, void* stream);
 
 /* table <-> PyG edge_index[2,E] int64 (row 0 = source j, row 1 = target i, grouped by i) */
 int gn_table_degree(const int32_t* nbr, const int32_t* ovf, int32_t N, int32_t K, int32_t* deg, void* stream);

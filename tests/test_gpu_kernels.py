@@ -685,3 +685,40 @@ def test_particlenet_backbone(oracle, name, mode, tol):
         forced_e = [t.edge_index().cpu() for t in tre["graphs"]]      # eval-mode features give their own graphs
         yeo = ref(b.x, forced_e[0], b.batch, b.n_pulses, forced_edges=forced_e)
     assert rel_err(ye, yeo) < (2e-4 if mode == 0 else 3e-2)
+
+
+def test_event_local_reverse_build_equals_global_build():
+    """gn_rev_build_events (one workgroup per event, LDS counters; scratch in HBM for events above 8192 pulses)
+    against gn_rev_build (global atomics): same offsets, same lists as sets, same hub nodes, hub lists sorted."""
+    import copy
+    from graphnet_amd import ops
+    torch.manual_seed(0)
+    sizes = [3, 0, 700, 1, 9000, 40, 2]
+    ptr = [0]
+    for n in sizes:
+        ptr.append(ptr[-1] + n)
+    N = ptr[-1]
+    x = torch.rand(N, 3)
+    x[ptr[2]:ptr[2] + 300] = x[ptr[2]]                     # 300 pulses on one position: hubs + overflow rows
+    x[ptr[4] + 100:ptr[4] + 180] = x[ptr[4] + 100]
+    ptr_d = torch.tensor(ptr, dtype=torch.int32, device=DEV)
+    batch = ops.ptr_to_batch(ptr_d, N)
+    t = ops.knn_graph(x.to(DEV), [0, 1, 2], batch, ptr_d, 8)
+    g = copy.copy(t)
+    g.event_ptr = None
+    t.build_reverse()
+    g.build_reverse()
+    assert t.rev_ptr is not g.rev_ptr
+    assert torch.equal(t.rev_ptr, g.rev_ptr)
+    rp = t.rev_ptr.cpu().numpy()
+    a, b = t.rev_rows.cpu().numpy(), g.rev_rows.cpu().numpy()
+    deg = np.diff(rp)
+    assert deg.max() > 64
+    for j in np.nonzero(deg)[0]:
+        la, lb = a[rp[j]:rp[j + 1]], b[rp[j]:rp[j + 1]]
+        assert sorted(la.tolist()) == sorted(lb.tolist()), j
+        if deg[j] > 64:
+            assert np.all(np.diff(la) > 0) and np.all(np.diff(lb) > 0)          # hub lists are sorted ascending
+    na, nb_ = int(t.rev_nhubs[0]), int(g.rev_nhubs[0])
+    assert na == nb_ == int((deg > 64).sum())
+    assert sorted(t.rev_hubs[:na].cpu().tolist()) == sorted(g.rev_hubs[:nb_].cpu().tolist())
