@@ -187,7 +187,7 @@ class _DynEdgeFunction(torch.autograd.Function):
         wb.begin("fwd", wsig)
         graphs, PQs, masks = [], [], []
         knn_coords: List[Tensor] = []          # fp32 coordinates each re-built graph was computed from
-        plan = None
+        plan = cfg.get("plan")                  # built with the layer-1 graph, shared by every layer of the batch
         # Second HIP stream: the k-NN of layer l+1 (vector-ALU bound) runs beside the P|Q GEMM of layer l+1 (HBM
         # bound, needs only the features), the reverse adjacency of every graph (needed by the backward only)
         # beside the edge kernel.  Tensors crossing streams are kept alive until the streams have joined.
@@ -394,7 +394,7 @@ class _DynEdgeGenericFunction(torch.autograd.Function):
         x0 = ops.concat_globals(x, gv if G else None, batch, ops.round_up(F0, 32))
         xs: List[Tuple[Tensor, int]] = [(x0, F0)]
         graphs, saved, knn_coords = [], [], []
-        plan = None
+        plan = cfg.get("plan")
         nconv = cfg["nconv"]
         for l, (p1, p2) in enumerate(conv_p):
             W1, b1, W2, b2 = p1[0], p1[1], p2[0], p2[1]
@@ -738,7 +738,9 @@ class DynEdge(GNN):
             k = int(knn_k.reshape(-1)[0]) if isinstance(knn_k, Tensor) else int(knn_k)
             kc = _maybe(data, "knn_columns")
             cols = list(kc[0]) if isinstance(kc, list) and kc and isinstance(kc[0], (list, tuple)) else list(kc)
-        return ops.knn_graph(x, cols, batch32, ptr32, k, strict=self._knn_strict)
+        plan = ops.knn_plan(ptr32, int(x.shape[0]))
+        self.__dict__["_last_plan"] = plan
+        return ops.knn_graph(x, cols, batch32, ptr32, k, strict=self._knn_strict, plan=plan)
 
     def _weight_buffers(self) -> _WeightBuffers:
         wb = self.__dict__.get("_wbuf")
@@ -774,6 +776,7 @@ class DynEdge(GNN):
             raise RuntimeError("graphnet_amd.DynEdge runs on an MI355X (HIP) device only; move the batch to 'cuda'.")
         x = x.to(torch.float32)
         ptr32, batch32, n_pulses = self._csr(data, x)
+        self.__dict__["_last_plan"] = None
         g0 = self._layer0_graph(data, x, batch32, ptr32)
         gv = ops.graph_globals(x, ptr32, g0, n_pulses)
         cfg = {
@@ -783,7 +786,7 @@ class DynEdge(GNN):
             "globals": gv, "globals_after": self._add_global_variables_after_pooling,
             "features_subset": self._features_subset, "k": self._nb_neighbours, "strict": self._knn_strict,
             "pools": None if self._skip_readout else self._global_pooling_schemes,
-            "want_trace": return_trace, "wbuf": self._weight_buffers(), "side_stream": self._side_stream(x.device, int(x.shape[0])),
+            "want_trace": return_trace, "wbuf": self._weight_buffers(), "plan": self.__dict__.get("_last_plan"), "side_stream": self._side_stream(x.device, int(x.shape[0])),
         }
         if self._is_generic():
             cfg["act"] = "gelu" if isinstance(self._activation, torch.nn.GELU) else "relu"
