@@ -45,7 +45,7 @@ SIGNATURES = {
     "gn_colsum": (I32, [P, I64, I32, I32, P, P, I32, P]),
     "gn_reduce_slabs": (I32, [P, I32, I64, P, I32, P]),
     "gn_edgeconv_saved_bytes": (I64, [I32, I32, I32, I32]),
-    "gn_edgeconv_fwd": (I32, [I32, P, P, P, P, I32, I32, P, I32, P, P, I32, P, I64, P, P, I32, P, P]),
+    "gn_edgeconv_fwd": (I32, [I32, P, P, P, P, I32, I32, P, I32, I32, P, P, I32, P, I64, P, P, I32, P, P]),
     "gn_edgeconv_bwd": (I32, [I32, P, P, P, P, I32, I32, P, I32, I32, P, I64, P, P, I32, P, P, I64, P]),
     "gn_edgeconv_dw2_slabs": (I32, [I32, I32, I32, I32, I32]),
     "gn_edgeconv_dw2": (I32, [I32, P, P, P, P, I32, I32, P, I32, I32, I32, P, I64, P, P, P, P]),

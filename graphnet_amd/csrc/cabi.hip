@@ -158,14 +158,14 @@ int64_t gn_edgeconv_saved_bytes(int32_t N, int32_t K, int32_t H1p, int32_t H2) {
     return gn::saved_layout(N, gn::edge_slots(K), H1p, H2).total;
 }
 int gn_edgeconv_fwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
-                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, const void* W2p,
+                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H1, const void* W2p,
                     const float* b2, int32_t H2, void* out, int64_t ldo, float* coords, const int32_t* coord_cols_host,
                     int32_t ncoord, void* saved, void* stream) {
-    if (K < 1 || K > 32 || H1p % 32 || H2 < 1) return bad("gn_edgeconv_fwd", "need 1<=K<=32, H1p%32==0");
+    if (K < 1 || K > 32 || H1p % 32 || H2 < 1 || H1 < 1 || H1 > H1p) return bad("gn_edgeconv_fwd", "need 1<=K<=32, H1p%32==0, 1<=H1<=H1p");
     if ((reinterpret_cast<uintptr_t>(PQ) & 15) || (reinterpret_cast<uintptr_t>(W2p) & 15) ||
         (reinterpret_cast<uintptr_t>(saved) & 15)) return bad("gn_edgeconv_fwd", "alignment");
     if (ncoord < 0 || ncoord > 8 || (ncoord > 0 && coords && !coord_cols_host)) return bad("gn_edgeconv_fwd", "0..8 coordinate columns");
-    return fail(gn::launch_edge_fwd(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, W2p, b2, H2, out,
+    return fail(gn::launch_edge_fwd(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, H1, W2p, b2, H2, out,
                                     ldo, coords, coord_cols_host, ncoord, saved, S(stream)), "gn_edgeconv_fwd");
 }
 int32_t gn_edgeconv_dw2_slabs(int32_t mode, int32_t N, int32_t K, int32_t H1p, int32_t H2) {

@@ -645,7 +645,7 @@ long long edge_dw2_splits(long long rows) {
         default: { constexpr int S = 32; CALL; } break; \
     }
 
-hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
+hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, const void* W2p, const float* b2, int H2,
                               void* out, long long ldo, float* coords, const CoordCols& cc, unsigned char* maskB,
                               int num_cus, hipStream_t st);
 hipError_t launch_edge_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout,
@@ -695,7 +695,7 @@ static bool use_v2(int mode, const EdgeGraph& g, int H1p, int H2) {
 
 // out is float in mode 0 and bf16 in mode 1; coords (optional, [N][8] fp32) receives the columns
 // coord_cols[0..ncoord) of the fp32 result (the next layer's k-NN coordinates).
-hipError_t launch_edge_fwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2,
+hipError_t launch_edge_fwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H1, const void* W2p, const float* b2,
                            int H2, void* out, long long ldo, float* coords, const int* coord_cols, int ncoord,
                            void* saved, hipStream_t st) {
     if (H1p % BK || g.K > 32 || ncoord < 0 || ncoord > 8) return hipErrorInvalidValue;
@@ -710,7 +710,7 @@ hipError_t launch_edge_fwd(int mode, const EdgeGraph& g, const void* PQ, int H1p
     // bf16: persistent weights-stationary kernel for the table rows when the shape allows it
     const bool v2 = use_v2(mode, g, H1p, H2);
     if (v2) {
-        hipError_t e = launch_edge_fwd_v2(g, PQ, H1p, W2p, b2, H2, out, ldo, coords, cc, sb + L.off_maskB, device_cus(), st);
+        hipError_t e = launch_edge_fwd_v2(g, PQ, H1p, H1, W2p, b2, H2, out, ldo, coords, cc, sb + L.off_maskB, device_cus(), st);
         if (e != hipSuccess) return e;
     }
     return edge_fwd_t<__bf16>(g, PQ, H1p, W2p, b2, H2, out, ldo, coords, cc, words, !v2, st);

@@ -298,6 +298,269 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_fwd_v2_kernel(
 #undef GN_V2_WRITE_H
 }
 
+// ---- forward epilogue of one 32-row block (one wave, 32 columns): relu, slot sums, slot masks.
+// lane (r = column, h): registers 4c..4c+3 = rows 8c + 4h + (0..3).  vrow: bit (row - 4h) = row valid.
+// S = 8: the block holds 4 centres x 8 slots; this lane returns centres 2h, 2h+1: ssum[0..1], smsk = 2 bytes.
+// S = 16: 2 centres x 16 slots; this lane returns centre h: ssum[0], smsk = 16 bits.
+__device__ __forceinline__ unsigned int xor32_u(unsigned int x, int h) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);    // {(lo, lo), (hi, hi)}: no LDS crossbar
+    return h ? sw[0] : sw[1];
+}
+__device__ __forceinline__ float xor32_f(float x, int h) {
+    return __builtin_bit_cast(float, xor32_u(__builtin_bit_cast(unsigned int, x), h));
+}
+// The epilogue is written as 16 element steps + a combine so that a caller can place the pieces between MFMAs.
+struct FwdEpi { float sums[4]; unsigned int pack; };
+__device__ __forceinline__ void fwd_epi_init(FwdEpi& e) { e.sums[0] = e.sums[1] = e.sums[2] = e.sums[3] = 0.0f; e.pack = 0; }
+// element q (call in the order q = 15 .. 0).  The chain runs on the NEGATED weights, so y = -(pre-activation):
+// relu(x) = -min(y, 0) and [x > 0] is the sign bit of y as it stands (y = -0.0 cannot occur: y = acc + nbias with
+// nbias = -b2 added last, and a + b is -0.0 only for (-0.0) + (-0.0)): three instructions per element plus the bias.
+template <bool FAST>
+__device__ __forceinline__ void fwd_epi_elem(FwdEpi& e, float y, unsigned int vrow, int q) {
+    if constexpr (!FAST) y = ((vrow >> acc_row(q, 0)) & 1u) ? y : 1.0f;
+    e.sums[q >> 2] -= fminf(y, 0.0f);
+    e.pack = __builtin_amdgcn_alignbit(e.pack, __builtin_bit_cast(unsigned int, y), 31);
+}
+template <int S>
+__device__ __forceinline__ void fwd_epi_combine(const FwdEpi& e, int h, float (&ssum)[2], unsigned int& smsk) {
+    const unsigned int other = xor32_u(e.pack, h);
+    const unsigned int lo16 = h ? other : e.pack, hi16 = h ? e.pack : other;   // slots 0-3 / 4-7
+    if constexpr (S == 8) {
+        smsk = 0;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const float mine = h ? e.sums[2 + cc] : e.sums[cc];
+            const float theirs = h ? e.sums[cc] : e.sums[2 + cc];
+            ssum[cc] = mine + xor32_f(theirs, h);
+            const int sh = 4 * (2 * h + cc);
+            smsk |= (((lo16 >> sh) & 0xFu) | (((hi16 >> sh) & 0xFu) << 4)) << (8 * cc);
+        }
+    } else {
+        const float own0 = e.sums[0] + e.sums[1], own1 = e.sums[2] + e.sums[3];
+        const float mine = h ? own1 : own0;
+        const float theirs = h ? own0 : own1;
+        ssum[0] = mine + xor32_f(theirs, h);
+        ssum[1] = 0.0f;
+        const int sh = 8 * h;
+        smsk = ((lo16 >> sh) & 0xFu) | (((hi16 >> sh) & 0xFu) << 4) |
+               (((lo16 >> (sh + 4)) & 0xFu) << 8) | (((hi16 >> (sh + 4)) & 0xFu) << 12);
+    }
+}
+template <int S, bool FAST>
+__device__ __forceinline__ void fwd_epi_block(const f32x16& acc, float nbias, unsigned int vrow, int h, float (&ssum)[2], unsigned int& smsk) {
+    FwdEpi e;
+    fwd_epi_init(e);
+#pragma unroll
+    for (int q = 15; q >= 0; --q) { const float y = acc[q] + nbias; fwd_epi_elem<FAST>(e, y, vrow, q); }
+    fwd_epi_combine<S>(e, h, ssum, smsk);
+}
+// one MFMA chain (32 rows x 32 columns, K = 16 * KSTEPS, A fragments from LDS two steps ahead) with the
+// epilogue of `pend` placed between the MFMAs: source order pinned by sched_barrier after every step.
+template <int KSTEPS, int S, bool FAST>
+__device__ __forceinline__ void fwd_phase(const unsigned char* a, const bf16x8 (&w2)[KSTEPS], float nbias, f32x16& acc_out,
+                                          const f32x16& pend, unsigned int vrow, int h, float (&ssum)[2], unsigned int& smsk) {
+    constexpr int EPS = (16 + KSTEPS - 1) / KSTEPS;         // epilogue elements per step: 1 (K >= 256), 2 (K = 128)
+    f32x16 acc;                                     // starts at 0 (inline constant): the bias is added in the epilogue, a
+    zero_acc(acc);                                  // bias-filled start value would sit in 16 more registers all loop long
+    FwdEpi e;
+    fwd_epi_init(e);
+    constexpr int PF = KSTEPS >= 22 ? 1 : 2;          // A fragments in flight ahead of the MFMA (register budget)
+    bf16x8 f[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) f[s] = *reinterpret_cast<const bf16x8*>(a + s * 32);
+    bool combined = false;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        if (s + PF < KSTEPS) f[s + PF] = *reinterpret_cast<const bf16x8*>(a + (s + PF) * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[s], w2[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < EPS; ++i) {
+            const int q = 15 - (s * EPS + i);
+            if (q >= 0) { const float y = pend[q] + nbias; fwd_epi_elem<FAST>(e, y, vrow, q); }
+        }
+        if (s * EPS >= 16 && !combined) { fwd_epi_combine<S>(e, h, ssum, smsk); combined = true; }
+        // pin the step: the accumulator chain and the epilogue state pass through an empty asm, so neither the
+        // IR passes nor the instruction schedulers can sink the vector work behind the MFMA chain
+        asm volatile("" : "+v"(acc), "+v"(e.pack), "+v"(e.sums[0]), "+v"(e.sums[1]), "+v"(e.sums[2]), "+v"(e.sums[3]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!combined) fwd_epi_combine<S>(e, h, ssum, smsk);
+    acc_out = acc;
+}
+
+// =============================================================================== forward, wave-specialised
+// Same tile, operand layout and results as edge_fwd_v2_kernel, but the two halves of the work run on DIFFERENT
+// waves so that the matrix core and the vector ALU of a SIMD are busy at the same time (in the kernel above the
+// two waves of a SIMD run gather / MFMA / epilogue phases in lockstep and the pipes take turns):
+//   * waves 0-7  = consumers: stationary W2 slice, 44 MFMAs per tile from the LDS tile, relu / slot-sum / slot-mask
+//     epilogue, output stores;
+//   * waves 8-11 = producers (one per SIMD beside two consumers): gather P[i], Q[j] of the NEXT tile (4 threads per
+//     edge row, loads issued one whole tile ahead), h = relu(P + Q) -> the other LDS buffer.
+// One barrier per tile; 12 waves = 3 per SIMD (VGPR budget 168).
+constexpr int WS_THREADS = 768;
+// KSTEPS = H1p / 16 (row layout of P|Q and W2p), KUSE = ceil(H1 / 16) <= KSTEPS: the k-steps that hold real columns
+// (H1 = 336: 21 of 22: the last one is the packed layout's zero padding and is neither gathered nor multiplied).
+template <int KSTEPS, int KUSE, int S>
+__global__ __launch_bounds__(WS_THREADS) void edge_fwd_ws_kernel(
+    EdgeGraph g, const __bf16* __restrict__ PQ, const __bf16* __restrict__ W2p, const float* __restrict__ b2,
+    int H2, __bf16* __restrict__ out, long long ldo, float* __restrict__ coords, CoordCols ccols,
+    unsigned char* __restrict__ maskB, int ntiles)
+{
+    static_assert(S == 8 || S == 16, "8 or 16 slots per centre");
+    constexpr int NST = 16 / S;
+    constexpr int K = KSTEPS * 16;
+    constexpr int ROWB = K * 2 + 16;
+    constexpr int CHUNKS = KUSE * 2;                   // 16-byte chunks per row that are gathered
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][V2_ROWS * ROWB];
+    __shared__ int s_jc[2][V2_ROWS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long ldpq = 2LL * K;
+    const long long main_rows = (long long)g.N * S;
+    const int kslots = g.K;
+    const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    int tile = blockIdx.x * per;
+    const int tile_end = min(ntiles, tile + per);
+
+    if (wave >= 8) {
+        // ------------------------------------------------------------------ producer
+        constexpr int NI = (CHUNKS + 3) / 4;             // 16-byte chunks per thread (4 threads per row)
+        const int ptid = tid - 512;
+        const int grow = ptid >> 2, gc0 = ptid & 3;
+        u32x4 preg[NI], qreg[NI];
+#define GN_WS_GATHER(ic_, jc_)                                                                        \
+    {                                                                                                 \
+        const int js__ = (jc_) < 0 ? 0 : (jc_);                                                       \
+        const __bf16* pp__ = PQ + (long long)(ic_) * ldpq;                                            \
+        const __bf16* qq__ = PQ + (long long)js__ * ldpq + K;                                         \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
+            const int c__ = gc0 + 4 * i;                                                              \
+            const int cc__ = c__ < CHUNKS ? c__ : CHUNKS - 1;                                         \
+            preg[i] = *reinterpret_cast<const u32x4*>(pp__ + cc__ * 8);                               \
+            qreg[i] = *reinterpret_cast<const u32x4*>(qq__ + cc__ * 8);                               \
+        }                                                                                             \
+    }
+#define GN_WS_WRITE_H(buf_)                                                                           \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
+            const int c__ = gc0 + 4 * i;                                                              \
+            const int cc__ = c__ < CHUNKS ? c__ : CHUNKS - 1;                                         \
+            *reinterpret_cast<u32x4*>(&As[buf_][grow * ROWB + cc__ * 16]) = relu_sum_bf16x8(preg[i], qreg[i]); \
+        }                                                                                             \
+    }
+        int ic_n, jc_n;                                   // row info of the tile whose chunks are in flight
+        {
+            int ic, jc;
+            GN_V2_INFO(tile, ic, jc);
+            GN_WS_GATHER(ic, jc);
+            GN_V2_INFO(tile + 1, ic_n, jc_n);
+            GN_WS_WRITE_H(0);
+            if (gc0 == 0) s_jc[0][grow] = jc;
+            GN_WS_GATHER(ic_n, jc_n);
+        }
+        __syncthreads();
+        int buf = 0;
+        for (; tile < tile_end; ++tile, buf ^= 1) {
+            int ic_nn, raw_nn;
+            bool ok_nn;
+            GN_V2_INFO_ISSUE(tile + 2, ic_nn, raw_nn, ok_nn);     // issued before, consumed after the tile's work
+            GN_WS_WRITE_H(buf ^ 1);                               // chunks of tile + 1 (loaded one tile ago)
+            if (gc0 == 0) s_jc[buf ^ 1][grow] = jc_n;
+            ic_n = ic_nn; jc_n = ok_nn ? raw_nn : -1;
+            GN_WS_GATHER(ic_n, jc_n);                             // tile + 2: lands while the consumers run tile + 1
+            __syncthreads();
+        }
+#undef GN_WS_GATHER
+#undef GN_WS_WRITE_H
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    // Software pipeline: the epilogue (vector ALU) of one 32-row block is interleaved, instruction by
+    // instruction, with the MFMA chain of the NEXT block of the same wave (phase A: rows 0-31 of tile t beside
+    // the epilogue of rows 32-63 of tile t-1; phase B: rows 32-63 beside the epilogue of rows 0-31), so the
+    // vector instructions issue in the 24 free cycles of every 32-cycle MFMA slot instead of after the chain.
+    const int r = lane & 31, h = lane >> 5;
+    const bool wave_on = wave * 32 < H2;
+    bf16x8 w2[KUSE];                                 // NEGATED W2 slice (see fwd_epi_elem)
+#pragma unroll
+    for (int s = 0; s < KUSE; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w2[s][e] = (__bf16)0.0f;
+    if (wave_on) {
+        const __bf16* wrow = W2p + (long long)(wave * 32 + r) * K + h * 8;
+#pragma unroll
+        for (int s = 0; s < KUSE; ++s) {
+            const u32x4 wv = *reinterpret_cast<const u32x4*>(wrow + s * 16) ^ (u32x4){0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+            w2[s] = __builtin_bit_cast(bf16x8, wv);
+        }
+    }
+    const int col = wave * 32 + r;
+    const float bias = (col < H2) ? -b2[col] : 0.0f;     // negated bias
+    int coord_d = -1;
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+        if (coords && d < ccols.n && ccols.c[d] == col) coord_d = d;
+    const bool is_coord = coord_d >= 0;
+    const int tile0 = tile;
+    __syncthreads();
+
+    // stores of one row block's results: S = 8: centres 2h, 2h+1 of the block; S = 16: centre h
+#define GN_WS_STORE(tile_, rb_, ssum_, smsk_)                                                         \
+    {                                                                                                 \
+        const int c0t__ = (tile_) * (V2_ROWS / S) + (rb_) * (32 / S) + NST * h;                       \
+        _Pragma("unroll") for (int c2 = 0; c2 < NST; ++c2) {                                          \
+            const int centre = c0t__ + c2;                 /* 32-bit element offsets off uniform bases */ \
+            if (centre < g.N) {                                                                       \
+                out[(unsigned int)centre * ldo32 + (unsigned int)col] = (__bf16)ssum_[c2];            \
+                const unsigned int mo__ = (unsigned int)centre * (unsigned int)H2 + (unsigned int)col; \
+                if constexpr (S == 8) maskB[mo__] = (unsigned char)((smsk_) >> (8 * c2));              \
+                else reinterpret_cast<unsigned short*>(maskB)[mo__] = (unsigned short)(smsk_);        \
+                if (is_coord) coords[(unsigned int)centre * 8u + (unsigned int)coord_d] = ssum_[c2];  \
+            }                                                                                         \
+        }                                                                                             \
+    }
+    const unsigned int ldo32 = (unsigned int)ldo;
+
+    f32x16 accP;                                     // rows 32-63 of the previous tile, epilogue pending
+    zero_acc(accP);
+    unsigned int vrowP = 0;
+    bool fastP = false;                              // wave-uniform: every row of that block valid
+    int buf = 0;
+    for (; tile < tile_end; ++tile, buf ^= 1) {
+        if (wave_on) {
+            const unsigned long long vbits = __ballot(s_jc[buf][lane] >= 0);      // bit = tile row valid
+            const unsigned int vrow0 = (unsigned int)(vbits >> (4 * h));
+            const unsigned int vrow1 = (unsigned int)(vbits >> (32 + 4 * h));
+            const unsigned char* a0 = &As[buf][r * ROWB + h * 16];
+            f32x16 acc0, acc1;
+            float sumP[2], sum0[2];
+            unsigned int mskP, msk0;
+            if (fastP)
+                fwd_phase<KUSE, S, true>(a0, w2, bias, acc0, accP, vrowP, h, sumP, mskP);
+            else
+                fwd_phase<KUSE, S, false>(a0, w2, bias, acc0, accP, vrowP, h, sumP, mskP);
+            if ((unsigned int)vbits == 0xffffffffu)
+                fwd_phase<KUSE, S, true>(a0 + 32 * ROWB, w2, bias, acc1, acc0, vrow0, h, sum0, msk0);
+            else
+                fwd_phase<KUSE, S, false>(a0 + 32 * ROWB, w2, bias, acc1, acc0, vrow0, h, sum0, msk0);
+            if (tile > tile0) GN_WS_STORE(tile - 1, 1, sumP, mskP);
+            GN_WS_STORE(tile, 0, sum0, msk0);
+            accP = acc1;
+            vrowP = vrow1;
+            fastP = (unsigned int)(vbits >> 32) == 0xffffffffu;
+        }
+        __syncthreads();
+    }
+    if (wave_on && tile_end > tile0) {               // drain: rows 32-63 of the last tile
+        float sumP[2];
+        unsigned int mskP;
+        fwd_epi_block<S, false>(accP, bias, vrowP, h, sumP, mskP);
+        GN_WS_STORE(tile_end - 1, 1, sumP, mskP);
+    }
+#undef GN_WS_STORE
+}
+
 // =============================================================================== dW2 / db2 / hbits
 // LDS pitch for tiles read with ds_read_b64_tr_b16: 4 consecutive rows must hit disjoint 64-byte
 // bank ranges -> pitch == 64 (mod 256).
@@ -722,11 +985,20 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
 // hipErrorNotSupported = shape outside the v2 envelope (caller falls back to the generic kernels)
 int edge_slots(int K);
 static inline int v2_tiles(const EdgeGraph& g) { return (int)(((long long)g.N * edge_slots(g.K) + V2_ROWS - 1) / V2_ROWS); }
+// wave-specialised variants: GN_EDGE_WS is a bit mask (1 = fwd), default on
+static bool ws_enabled(int which) {
+    static int mask = -1;
+    if (mask < 0) {
+        const char* e = getenv("GN_EDGE_WS");
+        mask = e ? atoi(e) : 7;
+    }
+    return (mask >> which) & 1;
+}
 bool edge_v2_shape_ok(int K, int H1p, int H2) {
     return K <= 16 && H2 == 256 && (H1p == 128 || H1p == 352);
 }
 
-hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
+hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, const void* W2p, const float* b2, int H2,
                               void* out, long long ldo, float* coords, const CoordCols& cc, unsigned char* maskB,
                               int num_cus, hipStream_t st) {
     if (!edge_v2_shape_ok(g.K, H1p, H2)) return hipErrorNotSupported;
@@ -736,10 +1008,20 @@ hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, const
 #define GN_FWD_LAUNCH(KS, SS)                                                                              \
     hipLaunchKernelGGL((edge_fwd_v2_kernel<KS, SS>), dim3(grid), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,  \
                        (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, coords, cc, maskB, ntiles)
+#define GN_FWD_LAUNCH_WS(KS, KU, SS)                                                                       \
+    hipLaunchKernelGGL((edge_fwd_ws_kernel<KS, KU, SS>), dim3(grid), dim3(WS_THREADS), 0, st, g, (const __bf16*)PQ,  \
+                       (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, coords, cc, maskB, ntiles)
     const bool s8 = edge_slots(g.K) == 8;
+    if (ws_enabled(0) && (long long)g.N * (ldo > H2 ? ldo : H2) < (1LL << 31)) {   // 32-bit store offsets
+        if (H1p == 128) { if (s8) GN_FWD_LAUNCH_WS(8, 8, 8); else GN_FWD_LAUNCH_WS(8, 8, 16); }
+        else if (H1 <= 336) { if (s8) GN_FWD_LAUNCH_WS(22, 21, 8); else GN_FWD_LAUNCH_WS(22, 21, 16); }
+        else { if (s8) GN_FWD_LAUNCH_WS(22, 22, 8); else GN_FWD_LAUNCH_WS(22, 22, 16); }
+        return hipGetLastError();
+    }
     if (H1p == 128) { if (s8) GN_FWD_LAUNCH(8, 8); else GN_FWD_LAUNCH(8, 16); }
     else { if (s8) GN_FWD_LAUNCH(22, 8); else GN_FWD_LAUNCH(22, 16); }
 #undef GN_FWD_LAUNCH
+#undef GN_FWD_LAUNCH_WS
     return hipGetLastError();
 }
 

@@ -39,7 +39,7 @@ hipError_t launch_reduce_slabs(const float* slab, int nslab, long long count, fl
 // edgeconv.hip
 int edge_slots(int K);
 long long edge_dw2_splits(long long rows);
-hipError_t launch_edge_fwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2,
+hipError_t launch_edge_fwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H1, const void* W2p, const float* b2,
                            int H2, void* out, long long ldo, float* coords, const int* coord_cols, int ncoord,
                            void* saved, hipStream_t st);
 hipError_t launch_edge_bwd(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H2, const void* gout,

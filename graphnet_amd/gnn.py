@@ -221,7 +221,7 @@ class _DynEdgeFunction(torch.autograd.Function):
                     plan = ops.knn_plan(ptr, N)               # query-tile plan: once per batch, all layers
                 if lowp and len(cols) <= 8:
                     # bf16 activations: the k-NN coordinates leave the kernel as a separate fp32 copy
-                    out, mask, coords = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2.contiguous(), H2, coord_cols=cols)
+                    out, mask, coords = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2.contiguous(), H2, coord_cols=cols, H1=H1)
                     if side is not None:
                         keep.append(coords)
                         side.wait_stream(main)
@@ -235,12 +235,12 @@ class _DynEdgeFunction(torch.autograd.Function):
                                                strict=cfg["strict"], plan=plan)
                     knn_coords.append(coords[:, :len(cols)])
                 else:
-                    out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2.contiguous(), H2)
+                    out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2.contiguous(), H2, H1=H1)
                     src = out.float() if lowp else out
                     g_next = ops.knn_graph(src, cols, batch, ptr, cfg["k"], strict=cfg["strict"], plan=plan)
                     knn_coords.append(src[:, cols])
             else:
-                out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2.contiguous(), H2)
+                out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2.contiguous(), H2, H1=H1)
                 g_next = None
             graphs.append(g); PQs.append(PQ); masks.append(mask)
             xs.append((out, H2))

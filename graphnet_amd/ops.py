@@ -398,8 +398,9 @@ def colsum(X: Tensor, C: int, out: Optional[Tensor] = None, accum: bool = False)
 
 # ------------------------------------------------------------------------------ EdgeConv
 def edgeconv_fwd(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, W2p: Tensor, b2: Tensor, H2: int,
-                 out: Optional[Tensor] = None, coord_cols: Optional[Sequence[int]] = None):
-    """``out[i] = sum_j relu(relu(P[i]+Q[j]) W2^T + b2)``; returns (out [N,H2] in the mode's activation
+                 out: Optional[Tensor] = None, coord_cols: Optional[Sequence[int]] = None, H1: Optional[int] = None):
+    """``out[i] = sum_j relu(relu(P[i]+Q[j]) W2^T + b2)``; ``H1`` (default ``H1p``) is the real hidden width:
+    columns ``H1..H1p-1`` of P, Q and W2p are the packed layout's zero padding.  Returns (out [N,H2] in the mode's activation
     type, relu bit mask) or, with ``coord_cols`` (<= 8 output columns), (out, mask, coords fp32 [N, 8])
     where ``coords[:, d]`` is the fp32 value of column ``coord_cols[d]`` (next layer's k-NN input)."""
     _need(PQ, mode_dtype(mode), "PQ"); _need(W2p, mode_dtype(mode), "W2p"); _need(b2, torch.float32, "b2")
@@ -417,7 +418,7 @@ def edgeconv_fwd(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, W2p: Tensor
         coords = torch.zeros((max(N, 1), 8), dtype=torch.float32, device=PQ.device)
         cc = (ctypes.c_int32 * max(nc, 1))(*[int(c) for c in coord_cols])
     with _timed("edgeconv_fwd"):
-        _lib.check(_lib.lib().gn_edgeconv_fwd(mode, *g.c_args(), _p(PQ), H1p, _p(W2p), _p(b2), H2, _p(out),
+        _lib.check(_lib.lib().gn_edgeconv_fwd(mode, *g.c_args(), _p(PQ), H1p, H1p if H1 is None else int(H1), _p(W2p), _p(b2), H2, _p(out),
                                               _rows(out, "out"), _p(coords),
                                               None if cc is None else ctypes.cast(cc, ctypes.c_void_p), nc,
                                               _p(mask), _st()))

@@ -135,9 +135,10 @@ int64_t gn_edgeconv_saved_bytes(int32_t N, int32_t K, int32_t H1p, int32_t H2);
 /* out[i, :H2] = sum_slots relu(relu(P[i]+Q[j]) . W2^T + b2); PQ: T[N, 2*H1p]; W2p: T[ceil128(H2)][H1p];
  * out: T[N, ldo].  coords (optional): fp32 [N][8], coords[i][d] = the fp32 value of output column
  * coord_cols_host[d], d < ncoord <= 8 — the coordinates DynEdgeConv re-runs k-NN on (layers.py:63-67),
- * kept in fp32 beside a bf16 `out`. */
+ * kept in fp32 beside a bf16 `out`.  H1 <= H1p = real hidden width: columns H1..H1p-1 of P, Q and W2p are
+ * zero padding (the packed layout), so the contraction may stop at H1. */
 int gn_edgeconv_fwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre, const int32_t* ovf_src,
-                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p,
+                    const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H1,
                     const void* W2p, const float* b2, int32_t H2, void* out, int64_t ldo,
                     float* coords, const int32_t* coord_cols_host, int32_t ncoord,
                     void* saved, void* stream);

@@ -47,7 +47,7 @@ def test_argument_validation_returns_error_codes_without_launching(lib):
     # bad shapes are rejected on the host before any kernel launch
     rc = lib.gn_knn_graph(None, 3, None, 3, None, None, 1, 10, 0, 0, None, None, None)
     assert rc != 0 and b"gn_knn_graph" in lib.gn_last_error()
-    rc = lib.gn_edgeconv_fwd(1, None, None, None, None, 10, 8, None, 100, None, None, 256, None, 256, None, None, 0,
+    rc = lib.gn_edgeconv_fwd(1, None, None, None, None, 10, 8, None, 100, 100, None, None, 256, None, 256, None, None, 0,
                              None, None)
     assert rc != 0 and b"H1p%32" in lib.gn_last_error()
     rc = lib.gn_graph_globals(None, 7, 3, None, 1, None, None, 8, None, None, None)

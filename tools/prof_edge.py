@@ -35,7 +35,7 @@ PQ = ops.linear_fwd(mode, [(x, F)], ops.pack_weight(Wpq, [F], dt, ops.gemm_kunit
 W2p = ops.pack_weight(W2, [H1], dt)
 W2Tp = ops.pack_weight(W2.t().contiguous(), [H2], dt)
 gout = torch.randn(N, H2, device=dev).to(dt)
-out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2)
+out, mask = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2, H1=H1)
 ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, gout, mask)
 dPQ = torch.empty(N, 2 * H1p, dtype=dt, device=dev)
 dpre = torch.empty(g.rows, H1p, dtype=dt, device=dev)
@@ -43,7 +43,7 @@ torch.cuda.synchronize()
 ops.enable_timers(True)
 for _ in range(iters):
     if what in ("fwd", "all"):
-        ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2)
+        ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2, H1=H1)
     if what in ("dw2", "all"):
         ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, gout, mask)
     if what in ("bwd", "all"):
