@@ -55,16 +55,19 @@ __device__ __forceinline__ u32x4 relu_sum_bf16x8(u32x4 p, u32x4 q) {
     }
     return o;
 }
-// 8 "h > 0" flags of a packed NON-NEGATIVE bf16x8 (bit c = column c of the chunk).  For a half in
-// [0, 0x7fff]: half != 0  <=>  bit 15 of (half + 0x7fff); the low half never carries into the high.
+// 8 "h > 0" flags of a packed NON-NEGATIVE bf16x8 (bit c = column c of the chunk): min(half, 1) is the flag of a
+// half in [0, 0x7fff]; a 16-bit dot product with the weights (2^2w, 2^(2w+1)) drops both flags of a dword into place:
+// two instructions per dword.
 __device__ __forceinline__ unsigned int nonzero_bits_bf16x8(u32x4 o) {
     unsigned int t = 0;
 #pragma unroll
-    for (int w = 3; w >= 0; --w) {
-        const unsigned int y = o[w] + 0x7fff7fffu;
-        t = (t << 2) | ((y >> 15) & 0x00010001u);
+    for (int w = 0; w < 4; ++w) {
+        unsigned int y;
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(y) : "v"(o[w]), "s"(0x00010001u));       // the compiler expands the builtin min
+        const unsigned int c = (1u << (2 * w)) | (2u << (2 * w + 16));
+        t = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, y), __builtin_bit_cast(u16x2, c), t, false);
     }
-    return (t & 0x55u) | ((t >> 15) & 0xAAu);
+    return t;
 }
 
 // ---- shared gather machinery (8 threads per row, thread handles 16-byte chunks (tid&7)+8i) --------
@@ -590,6 +593,7 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
     constexpr int CHUNKS = K / 8;
     constexpr int NI = (NBH * 4 + 7) / 8;           // 16-byte chunks per thread (8 threads per row)
     constexpr int HP = tr_pitch(NBH * 64);
+    constexpr int CPT = V2_ROWS / S;                // centres per tile
     __shared__ __attribute__((aligned(16))) unsigned char Hs[2][V2_ROWS * HP];
     __shared__ __attribute__((aligned(16))) unsigned char MaskLut[256 * 16];   // byte -> 8 x (0 / 0xFFFF) halfwords
 
@@ -602,8 +606,6 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
             e[jj] = ((tid >> (2 * jj)) & 1 ? 0x0000ffffu : 0u) | ((tid >> (2 * jj + 1)) & 1 ? 0xffff0000u : 0u);
         *reinterpret_cast<u32x4*>(&MaskLut[tid * 16]) = e;
     }
-    const long long ldpq = 2LL * K;
-    const long long main_rows = (long long)g.N * S;
     const bool wave_on = wave * 32 < H2;
     const int kslots = g.K;
     const int n2 = wave * 32 + r;                   // dm column owned by this lane (A rows)
@@ -612,68 +614,106 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
     const int nparts = ((int)gridDim.x + HALVES - 1) / HALVES;
     const int kb0 = half * NBH;
     const int nblk = (NB1 - kb0) < NBH ? (NB1 - kb0) : NBH;       // k1 blocks of this workgroup
-    const int cbeg = kb0 * 4, cend = (kb0 + nblk) * 4;             // its chunk window
+    const int cbeg = kb0 * 4;
+    const int cend_all = (kb0 + nblk) * 4;                          // chunk window of this workgroup's k1 blocks ...
+    const int creal = (H1 + 7) / 8;                                 // ... of which only chunks < ceil(H1 / 8) hold real
+    const int cend = cend_all < creal ? cend_all : creal;           // columns: the zero padding is not gathered
 
     f32x16 acc[NBH];
 #pragma unroll
     for (int nb = 0; nb < NBH; ++nb) zero_acc(acc[nb]);
     float bsum = 0.0f;
 
+    // ---- addressing: 32-bit offsets off the (uniform) base pointers, advanced by constants from tile to tile
+    // (no 64-bit multiplies in the loop; the launcher checks that every offset fits)
     const int grow = tid >> 3, gc0 = tid & 7;
+    const int sl = grow % S, slc = sl < kslots ? sl : 0;
+    const bool slot_ok = sl < kslots;
+    constexpr unsigned int ROWPQ = 2u * K * 2u;                    // bytes per P|Q row
+    const unsigned char* PQb = reinterpret_cast<const unsigned char*>(PQ);
+    const unsigned char* goutb = reinterpret_cast<const unsigned char*>(gout);
+    const unsigned int ldg2 = (unsigned int)ldg * 2u;              // bytes per g_out row
     u32x4 preg[NI], qreg[NI];
-// All gathered chunks are consumed (-> LDS) before the first hbits store is issued: vmcnt retires in order,
-// so a store queued between two consumed loads would make the later wait include that store's write ack.
-#define GN_V2_WRITE_HT(buf_, tile_)                                                                   \
-    {                                                                                                 \
-        const long long rowg__ = (long long)(tile_) * V2_ROWS + grow;                                 \
-        const bool rok__ = (tile_) < ntiles && rowg__ < main_rows;                                    \
-        unsigned int hb__[NI];                                                                        \
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
-            const int c__ = cbeg + gc0 + 8 * i;                                                       \
-            const int cc__ = c__ < cend ? c__ : cend - 1;                                             \
-            const u32x4 hv__ = relu_sum_bf16x8(preg[i], qreg[i]);                                     \
-            *reinterpret_cast<u32x4*>(&Hs[buf_][grow * HP + (cc__ - cbeg) * 16]) = hv__;              \
-            hb__[i] = nonzero_bits_bf16x8(hv__);                                                      \
-        }                                                                                             \
-        if (rok__) {                                                                                  \
-            _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                          \
-                const int c__ = cbeg + gc0 + 8 * i;                                                   \
-                const int cc__ = c__ < cend ? c__ : cend - 1;                                         \
-                hbits[rowg__ * CHUNKS + cc__] = (unsigned char)hb__[i];                               \
-            }                                                                                         \
-        }                                                                                             \
-    }
-    // A-side operands of one tile: k-step s covers 16 edge rows, lane half h their rows 8h..8h+7 = eight
-    // slots of ONE centre: centre 8*tile + 2s + h (S = 8) or centre 4*tile + s, slots 8h.. (S = 16).
-    // The lane needs g_out and those 8 slot bits at column n2; the four bytes are packed into one register
-#define GN_V2_LOAD_A(tile_, gv_, mv_)                                                                 \
-    {                                                                                                 \
-        (mv_) = 0u;                                                                                   \
-        _Pragma("unroll") for (int s = 3; s >= 0; --s) {                                              \
-            const long long c__ = (S == 8) ? (long long)(tile_) * 8 + 2 * s + h : (long long)(tile_) * 4 + s; \
-            const bool ok__ = (tile_) < ntiles && c__ < g.N && n2 < H2;                               \
-            const long long cs__ = ok__ ? c__ : 0;                                                    \
-            const float gl__ = (float)gout[cs__ * ldg + n2c];                                         \
-            const unsigned int ml__ = (S == 8) ? (unsigned int)maskB[cs__ * H2 + n2c]                 \
-                                               : (unsigned int)maskB[(cs__ * H2 + n2c) * 2 + h];      \
-            gv_[s] = ok__ ? gl__ : 0.0f;                                                              \
-            (mv_) = ((mv_) << 8) | (ok__ ? ml__ : 0u);                                                \
-        }                                                                                             \
+    int cc_[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const int c = cbeg + gc0 + 8 * i; cc_[i] = c < cend ? c : cend - 1; }
+    // pad columns of this workgroup's window (chunks cend .. cend_all-1): zero once in both buffers, never written again
+    for (int idx = tid; idx < 2 * V2_ROWS * (cend_all - cend); idx += V2_THREADS) {
+        const int bufz = idx / (V2_ROWS * (cend_all - cend)), rem = idx % (V2_ROWS * (cend_all - cend));
+        const int rowz = rem / (cend_all - cend), cz = cend + rem % (cend_all - cend);
+        *reinterpret_cast<u32x4*>(&Hs[bufz][rowz * HP + (cz - cbeg) * 16]) = (u32x4){0u, 0u, 0u, 0u};
     }
 
     const int per = (ntiles + nparts - 1) / nparts;
     int tile = part * per;
     const int tile_end = min(ntiles, tile + per);
-    int ic_n, jc_n;
+
+// row info of tile T: centre ii, neighbour raw (loaded), validity
+#define GN_D_INFO_ISSUE(T_, ii_, raw_, ok_)                                                           \
+    {                                                                                                 \
+        const int iiu__ = (T_) * CPT + grow / S;                                                      \
+        const bool inr__ = ((T_) < ntiles) && (iiu__ < g.N);                                          \
+        (ii_) = inr__ ? iiu__ : 0;                                                                    \
+        (raw_) = g.nbr[(unsigned int)(ii_) * (unsigned int)kslots + (unsigned int)slc];               \
+        (ok_) = inr__ && slot_ok;                                                                     \
+    }
+#define GN_D_GATHER(ii_, jc_)                                                                         \
+    {                                                                                                 \
+        const unsigned int js__ = (jc_) < 0 ? 0u : (unsigned int)(jc_);                               \
+        const unsigned int po__ = __umul24((unsigned int)(ii_), ROWPQ);               \
+        const unsigned int qo__ = __umul24(js__, ROWPQ) + 2u * K;                     \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
+            preg[i] = *reinterpret_cast<const u32x4*>(PQb + po__ + (unsigned int)cc_[i] * 16u);       \
+            qreg[i] = *reinterpret_cast<const u32x4*>(PQb + qo__ + (unsigned int)cc_[i] * 16u);       \
+        }                                                                                             \
+    }
+// All gathered chunks are consumed (-> LDS) before the first hbits store is issued: vmcnt retires in order,
+// so a store queued between two consumed loads would make the later wait include that store's write ack.
+#define GN_D_WRITE_HT(buf_, T_)                                                                       \
+    {                                                                                                 \
+        const int rowu__ = (T_) * V2_ROWS + grow;                                                     \
+        const bool rok__ = (T_) < ntiles && rowu__ / S < g.N;                                         \
+        unsigned int hb__[NI];                                                                        \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
+            const u32x4 hv__ = relu_sum_bf16x8(preg[i], qreg[i]);                                     \
+            *reinterpret_cast<u32x4*>(&Hs[buf_][grow * HP + (cc_[i] - cbeg) * 16]) = hv__;            \
+            hb__[i] = nonzero_bits_bf16x8(hv__);                                                      \
+        }                                                                                             \
+        if (rok__) {                                                                                  \
+            const unsigned int ho__ = (unsigned int)rowu__ * (unsigned int)CHUNKS;                    \
+            _Pragma("unroll") for (int i = 0; i < NI; ++i) hbits[ho__ + (unsigned int)cc_[i]] = (unsigned char)hb__[i]; \
+        }                                                                                             \
+    }
+    // A-side operands of one tile: k-step s covers 16 edge rows, lane half h their rows 8h..8h+7 = eight
+    // slots of ONE centre: centre 8*tile + 2s + h (S = 8) or centre 4*tile + s, slots 8h.. (S = 16).
+    // The lane needs g_out and those 8 slot bits at column n2; the four bytes are packed into one register
+#define GN_D_LOAD_A(T_, gv_, mv_)                                                                     \
+    {                                                                                                 \
+        (mv_) = 0u;                                                                                   \
+        _Pragma("unroll") for (int s = 3; s >= 0; --s) {                                              \
+            const int c__ = (S == 8) ? (T_) * 8 + 2 * s + h : (T_) * 4 + s;                           \
+            const bool ok__ = (T_) < ntiles && c__ < g.N && n2 < H2;                                  \
+            const unsigned int cs__ = ok__ ? (unsigned int)c__ : 0u;                                  \
+            const float gl__ = (float)*reinterpret_cast<const __bf16*>(goutb + cs__ * ldg2 + (unsigned int)n2c * 2u); \
+            const unsigned int mo__ = cs__ * (unsigned int)H2 + (unsigned int)n2c;                    \
+            const unsigned int ml__ = (S == 8) ? (unsigned int)maskB[mo__] : (unsigned int)maskB[mo__ * 2u + (unsigned int)h]; \
+            gv_[s] = ok__ ? gl__ : 0.0f;                                                              \
+            (mv_) = ((mv_) << 8) | (ok__ ? ml__ : 0u);                                                \
+        }                                                                                             \
+    }
+
+    int ii_n, jc_n;
     float ga[4], gb[4];
     unsigned int ma, mb;
     {
-        int ic, jc;
-        GN_V2_INFO(tile, ic, jc);
-        GN_V2_GATHER_WIN(ic, jc, cbeg, cend, NI);
-        GN_V2_INFO(tile + 1, ic_n, jc_n);
-        GN_V2_LOAD_A(tile, ga, ma);
-        GN_V2_WRITE_HT(0, tile);
+        int ii, raw; bool ok;
+        GN_D_INFO_ISSUE(tile, ii, raw, ok);
+        const int jc = ok ? raw : -1;
+        GN_D_GATHER(ii, jc);
+        GN_D_INFO_ISSUE(tile + 1, ii_n, raw, ok);
+        jc_n = ok ? raw : -1;
+        GN_D_LOAD_A(tile, ga, ma);
+        GN_D_WRITE_HT(0, tile);
     }
     __syncthreads();
 
@@ -683,11 +723,11 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
 
     int buf = 0;
     for (; tile < tile_end; ++tile, buf ^= 1) {
-        int ic_nn, raw_nn;
+        int ii_nn, raw_nn;
         bool ok_nn;
-        GN_V2_INFO_ISSUE(tile + 2, ic_nn, raw_nn, ok_nn);
-        GN_V2_LOAD_A(tile + 1, gb, mb);
-        GN_V2_GATHER_WIN(ic_n, jc_n, cbeg, cend, NI);
+        GN_D_INFO_ISSUE(tile + 2, ii_nn, raw_nn, ok_nn);
+        GN_D_LOAD_A(tile + 1, gb, mb);
+        GN_D_GATHER(ii_n, jc_n);
 
         if (wave_on) {
             const unsigned char* hb = &Hs[buf][tr_base];
@@ -716,15 +756,17 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
             }
         }
 
-        GN_V2_WRITE_HT(buf ^ 1, tile + 1);
-        ic_n = ic_nn; jc_n = ok_nn ? raw_nn : -1;
+        GN_D_WRITE_HT(buf ^ 1, tile + 1);
+        ii_n = ii_nn; jc_n = ok_nn ? raw_nn : -1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) ga[s] = gb[s];
         ma = mb;
         __syncthreads();
     }
-#undef GN_V2_WRITE_HT
-#undef GN_V2_LOAD_A
+#undef GN_D_INFO_ISSUE
+#undef GN_D_GATHER
+#undef GN_D_WRITE_HT
+#undef GN_D_LOAD_A
 
     // ---- write this workgroup's part of slab `part`: dW2[H2][k1 window] and (half 0) db2[H2]
     if (wave_on) {
@@ -1040,6 +1082,10 @@ hipError_t launch_edge_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H
                               float* db2_part, int num_cus, hipStream_t st) {
     if (!edge_v2_shape_ok(g.K, H1p, H2)) return hipErrorNotSupported;
     if (g.N == 0) return hipSuccess;
+    // the kernel addresses P|Q, g_out, the slot masks and hbits with 32-bit offsets (and 24-bit node ids)
+    if (g.N >= (1 << 24) || (long long)g.N * 4 * H1p >= (1LL << 32) || (long long)g.N * ldg * 2 >= (1LL << 32) ||
+        (long long)g.N * H2 * 2 >= (1LL << 32) || (long long)g.N * edge_slots(g.K) * (H1p / 8) >= (1LL << 32))
+        return hipErrorNotSupported;
     const int ntiles = v2_tiles(g);
     const int parts = edge_dw2_v2_parts(g.N, g.K, H1p, num_cus);
 #define GN_DW2_LAUNCH(A, B, C, SS, GRID)                                                                    \
