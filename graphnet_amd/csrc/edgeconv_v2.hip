@@ -312,34 +312,50 @@ __device__ __forceinline__ unsigned int xor32_u(unsigned int x, int h) {
 __device__ __forceinline__ float xor32_f(float x, int h) {
     return __builtin_bit_cast(float, xor32_u(__builtin_bit_cast(unsigned int, x), h));
 }
-// The epilogue is written as 16 element steps + a combine so that a caller can place the pieces between MFMAs.
-struct FwdEpi { float sums[4]; unsigned int pack; };
-__device__ __forceinline__ void fwd_epi_init(FwdEpi& e) { e.sums[0] = e.sums[1] = e.sums[2] = e.sums[3] = 0.0f; e.pack = 0; }
-// element q (call in the order q = 15 .. 0).  The chain runs on the NEGATED weights, so y = -(pre-activation):
-// relu(x) = -min(y, 0) and [x > 0] is the sign bit of y as it stands (y = -0.0 cannot occur: y = acc + nbias with
-// nbias = -b2 added last, and a + b is -0.0 only for (-0.0) + (-0.0)): three instructions per element plus the bias.
+// The epilogue is written as 8 element-pair steps + a combine so that a caller can place the pieces between MFMAs.
+// Two fp32 partial sums per centre group (even / odd rows) so that the bias add and the accumulation are PACKED
+// fp32 instructions (v_pk_add_f32: two elements per issue slot).
+struct FwdEpi { f32x2 sums[4]; unsigned int pack; };
+__device__ __forceinline__ void fwd_epi_init(FwdEpi& e) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) e.sums[c] = (f32x2){0.0f, 0.0f};
+    e.pack = 0;
+}
+// elements q, q-1 (q odd; call in the order q = 15, 13, .. 1).  The chain runs on the NEGATED weights, so
+// y = -(pre-activation): relu(x) = -min(y, 0) and [x > 0] is the sign bit of y as it stands (y = -0.0 cannot
+// occur: y = acc + nbias with nbias = -b2 added last, and a + b is -0.0 only for (-0.0) + (-0.0)).
 template <bool FAST>
-__device__ __forceinline__ void fwd_epi_elem(FwdEpi& e, float y, unsigned int vrow, int q) {
-    if constexpr (!FAST) y = ((vrow >> acc_row(q, 0)) & 1u) ? y : 1.0f;
-    e.sums[q >> 2] -= fminf(y, 0.0f);
-    e.pack = __builtin_amdgcn_alignbit(e.pack, __builtin_bit_cast(unsigned int, y), 31);
+__device__ __forceinline__ void fwd_epi_pair(FwdEpi& e, float a_hi, float a_lo, f32x2 nbias2, unsigned int vrow, int q) {
+    f32x2 y = (f32x2){a_hi, a_lo} + nbias2;
+    if constexpr (!FAST) {
+        y[0] = ((vrow >> acc_row(q, 0)) & 1u) ? y[0] : 1.0f;
+        y[1] = ((vrow >> acc_row(q - 1, 0)) & 1u) ? y[1] : 1.0f;
+    }
+    const float y0 = y[0], y1 = y[1];
+    const f32x2 m = {fminf(y0, 0.0f), fminf(y1, 0.0f)};
+    e.sums[q >> 2] -= m;
+    e.pack = __builtin_amdgcn_alignbit(e.pack, __builtin_bit_cast(unsigned int, y0), 31);
+    e.pack = __builtin_amdgcn_alignbit(e.pack, __builtin_bit_cast(unsigned int, y1), 31);
 }
 template <int S>
 __device__ __forceinline__ void fwd_epi_combine(const FwdEpi& e, int h, float (&ssum)[2], unsigned int& smsk) {
+    float sums[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const f32x2 v = e.sums[c]; sums[c] = v[0] + v[1]; }
     const unsigned int other = xor32_u(e.pack, h);
     const unsigned int lo16 = h ? other : e.pack, hi16 = h ? e.pack : other;   // slots 0-3 / 4-7
     if constexpr (S == 8) {
         smsk = 0;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            const float mine = h ? e.sums[2 + cc] : e.sums[cc];
-            const float theirs = h ? e.sums[cc] : e.sums[2 + cc];
+            const float mine = h ? sums[2 + cc] : sums[cc];
+            const float theirs = h ? sums[cc] : sums[2 + cc];
             ssum[cc] = mine + xor32_f(theirs, h);
             const int sh = 4 * (2 * h + cc);
             smsk |= (((lo16 >> sh) & 0xFu) | (((hi16 >> sh) & 0xFu) << 4)) << (8 * cc);
         }
     } else {
-        const float own0 = e.sums[0] + e.sums[1], own1 = e.sums[2] + e.sums[3];
+        const float own0 = sums[0] + sums[1], own1 = sums[2] + sums[3];
         const float mine = h ? own1 : own0;
         const float theirs = h ? own0 : own1;
         ssum[0] = mine + xor32_f(theirs, h);
@@ -353,21 +369,23 @@ template <int S, bool FAST>
 __device__ __forceinline__ void fwd_epi_block(const f32x16& acc, float nbias, unsigned int vrow, int h, float (&ssum)[2], unsigned int& smsk) {
     FwdEpi e;
     fwd_epi_init(e);
+    const f32x2 nb2 = {nbias, nbias};
 #pragma unroll
-    for (int q = 15; q >= 0; --q) { const float y = acc[q] + nbias; fwd_epi_elem<FAST>(e, y, vrow, q); }
+    for (int q = 15; q >= 1; q -= 2) { const float ah = acc[q], al = acc[q - 1]; fwd_epi_pair<FAST>(e, ah, al, nb2, vrow, q); }
     fwd_epi_combine<S>(e, h, ssum, smsk);
 }
-// one MFMA chain (32 rows x 32 columns, K = 16 * KSTEPS, A fragments from LDS two steps ahead) with the
-// epilogue of `pend` placed between the MFMAs: source order pinned by sched_barrier after every step.
+// one MFMA chain (32 rows x 32 columns, K = 16 * KSTEPS, A fragments from LDS ahead of use) with the
+// epilogue of `pend` placed between the MFMAs: source order pinned after every step.
 template <int KSTEPS, int S, bool FAST>
 __device__ __forceinline__ void fwd_phase(const unsigned char* a, const bf16x8 (&w2)[KSTEPS], float nbias, f32x16& acc_out,
                                           const f32x16& pend, unsigned int vrow, int h, float (&ssum)[2], unsigned int& smsk) {
-    constexpr int EPS = (16 + KSTEPS - 1) / KSTEPS;         // epilogue elements per step: 1 (K >= 256), 2 (K = 128)
+    constexpr int STRIDE = KSTEPS >= 16 ? 2 : 1;       // one element pair every STRIDE steps (8 pairs in all)
     f32x16 acc;                                     // starts at 0 (inline constant): the bias is added in the epilogue, a
     zero_acc(acc);                                  // bias-filled start value would sit in 16 more registers all loop long
     FwdEpi e;
     fwd_epi_init(e);
-    constexpr int PF = KSTEPS >= 22 ? 1 : 2;          // A fragments in flight ahead of the MFMA (register budget)
+    const f32x2 nb2 = {nbias, nbias};
+    constexpr int PF = KSTEPS >= 21 ? 1 : 2;          // A fragments in flight ahead of the MFMA (register budget)
     bf16x8 f[KSTEPS];
 #pragma unroll
     for (int s = 0; s < PF; ++s) f[s] = *reinterpret_cast<const bf16x8*>(a + s * 32);
@@ -376,12 +394,12 @@ __device__ __forceinline__ void fwd_phase(const unsigned char* a, const bf16x8 (
     for (int s = 0; s < KSTEPS; ++s) {
         if (s + PF < KSTEPS) f[s + PF] = *reinterpret_cast<const bf16x8*>(a + (s + PF) * 32);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[s], w2[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < EPS; ++i) {
-            const int q = 15 - (s * EPS + i);
-            if (q >= 0) { const float y = pend[q] + nbias; fwd_epi_elem<FAST>(e, y, vrow, q); }
+        if (s % STRIDE == 0 && s / STRIDE < 8) {
+            const int q = 15 - 2 * (s / STRIDE);
+            const float ah = pend[q], al = pend[q - 1];
+            fwd_epi_pair<FAST>(e, ah, al, nb2, vrow, q);
         }
-        if (s * EPS >= 16 && !combined) { fwd_epi_combine<S>(e, h, ssum, smsk); combined = true; }
+        if (s / STRIDE >= 8 && !combined) { fwd_epi_combine<S>(e, h, ssum, smsk); combined = true; }
         // pin the step: the accumulator chain and the epilogue state pass through an empty asm, so neither the
         // IR passes nor the instruction schedulers can sink the vector work behind the MFMA chain
         asm volatile("" : "+v"(acc), "+v"(e.pack), "+v"(e.sums[0]), "+v"(e.sums[1]), "+v"(e.sums[2]), "+v"(e.sums[3]));
@@ -418,7 +436,6 @@ __global__ __launch_bounds__(WS_THREADS) void edge_fwd_ws_kernel(
     __shared__ int s_jc[2][V2_ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long ldpq = 2LL * K;
     const long long main_rows = (long long)g.N * S;
     const int kslots = g.K;
     const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -431,24 +448,27 @@ __global__ __launch_bounds__(WS_THREADS) void edge_fwd_ws_kernel(
         const int ptid = tid - 512;
         const int grow = ptid >> 2, gc0 = ptid & 3;
         u32x4 preg[NI], qreg[NI];
+        // 32-bit byte offsets off the uniform base; chunk i sits at the immediate offset 64 * i from the thread's first
+        // chunk, except that the last round is clamped into the row (4 * NI may exceed CHUNKS)
+        const unsigned char* PQb = reinterpret_cast<const unsigned char*>(PQ);
+        constexpr unsigned int ROWPQ = 2u * K * 2u;
+        const unsigned int clast = (gc0 + 4 * (NI - 1) < CHUNKS ? gc0 + 4 * (NI - 1) : CHUNKS - 1) * 16u;
 #define GN_WS_GATHER(ic_, jc_)                                                                        \
     {                                                                                                 \
-        const int js__ = (jc_) < 0 ? 0 : (jc_);                                                       \
-        const __bf16* pp__ = PQ + (long long)(ic_) * ldpq;                                            \
-        const __bf16* qq__ = PQ + (long long)js__ * ldpq + K;                                         \
+        const unsigned int js__ = (jc_) < 0 ? 0u : (unsigned int)(jc_);                               \
+        const unsigned int po__ = __umul24((unsigned int)(ic_), ROWPQ);                               \
+        const unsigned int qo__ = __umul24(js__, ROWPQ) + 2u * K;                                     \
         _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
-            const int c__ = gc0 + 4 * i;                                                              \
-            const int cc__ = c__ < CHUNKS ? c__ : CHUNKS - 1;                                         \
-            preg[i] = *reinterpret_cast<const u32x4*>(pp__ + cc__ * 8);                               \
-            qreg[i] = *reinterpret_cast<const u32x4*>(qq__ + cc__ * 8);                               \
+            const unsigned int co__ = (i + 1 < NI) ? (unsigned int)gc0 * 16u + 64u * i : clast;       \
+            preg[i] = *reinterpret_cast<const u32x4*>(PQb + po__ + co__);                             \
+            qreg[i] = *reinterpret_cast<const u32x4*>(PQb + qo__ + co__);                             \
         }                                                                                             \
     }
 #define GN_WS_WRITE_H(buf_)                                                                           \
     {                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
-            const int c__ = gc0 + 4 * i;                                                              \
-            const int cc__ = c__ < CHUNKS ? c__ : CHUNKS - 1;                                         \
-            *reinterpret_cast<u32x4*>(&As[buf_][grow * ROWB + cc__ * 16]) = relu_sum_bf16x8(preg[i], qreg[i]); \
+            const unsigned int co__ = (i + 1 < NI) ? (unsigned int)gc0 * 16u + 64u * i : clast;       \
+            *reinterpret_cast<u32x4*>(&As[buf_][grow * ROWB + co__]) = relu_sum_bf16x8(preg[i], qreg[i]); \
         }                                                                                             \
     }
         int ic_n, jc_n;                                   // row info of the tile whose chunks are in flight
@@ -1054,7 +1074,8 @@ hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, int H
     hipLaunchKernelGGL((edge_fwd_ws_kernel<KS, KU, SS>), dim3(grid), dim3(WS_THREADS), 0, st, g, (const __bf16*)PQ,  \
                        (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, coords, cc, maskB, ntiles)
     const bool s8 = edge_slots(g.K) == 8;
-    if (ws_enabled(0) && (long long)g.N * (ldo > H2 ? ldo : H2) < (1LL << 31)) {   // 32-bit store offsets
+    if (ws_enabled(0) && (long long)g.N * (ldo > H2 ? ldo : H2) < (1LL << 31) && g.N < (1 << 24) &&
+        (long long)g.N * 4 * H1p < (1LL << 32)) {                                    // 32-bit offsets, 24-bit node ids
         if (H1p == 128) { if (s8) GN_FWD_LAUNCH_WS(8, 8, 8); else GN_FWD_LAUNCH_WS(8, 8, 16); }
         else if (H1 <= 336) { if (s8) GN_FWD_LAUNCH_WS(22, 21, 8); else GN_FWD_LAUNCH_WS(22, 21, 16); }
         else { if (s8) GN_FWD_LAUNCH_WS(22, 22, 8); else GN_FWD_LAUNCH_WS(22, 22, 16); }
