@@ -344,11 +344,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
     for (int i = 0; i < 4; ++i) zero_acc(acc[i]);
     zero_acc(accb);
 
-    // staging: 8 threads per row; thread handles 16-byte bf16 chunks (tid&7)+8j (8 columns each)
+    // staging: 8 threads per row; thread handles 16-byte bf16 chunks (tid&7)+8j (8 columns each).
+    // Two register sets: the rows of tile t+2 are requested while tile t is multiplied (one tile of MFMAs is
+    // ~1300 cycles, less than an HBM round trip under load: with a single set every iteration ended on the loads).
     const int srow = tid >> 3, sc = tid & 7;
-    Chunk8<DYT> yr[4];
-    Chunk8<XT> xr[2];
-#define GN_TN2_LOAD(t_)                                                                              \
+    Chunk8<DYT> yr0[4], yr1[4];
+    Chunk8<XT> xr0[2], xr1[2];
+#define GN_TN2_LOAD(t_, yr, xr)                                                                      \
     {                                                                                                \
         const int m__ = (t_) * TN2_ROWS + srow;                                                      \
         const bool mok__ = (t_) < tile_end && m__ < M;                                               \
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
             load_chunk8(xr[j], xp + ms__ * ldx, kcol0 + (sc + 8 * j) * 8, xw, mok__);                \
     }
-#define GN_TN2_WRITE(buf_)                                                                           \
+#define GN_TN2_WRITE(buf_, yr, xr)                                                                   \
     {                                                                                                \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
             *reinterpret_cast<u32x4*>(&Ys[buf_][srow * YP + (sc + 8 * j) * 16]) = pack_chunk8(yr[j]); \
@@ -367,8 +369,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
     }
     // out-of-range float4s are read from a clamped (valid) address and zeroed: branch-free staging
 
-    GN_TN2_LOAD(tile);
-    GN_TN2_WRITE(0);
+    GN_TN2_LOAD(tile, yr0, xr0);
+    GN_TN2_WRITE(0, yr0, xr0);
+    GN_TN2_LOAD(tile + 1, yr0, xr0);
+    GN_TN2_LOAD(tile + 2, yr1, xr1);
     __syncthreads();
 
     const int g4 = lane >> 4, li = lane & 15;
@@ -379,32 +383,39 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
-    int buf = 0;
-    for (; tile < tile_end; ++tile, buf ^= 1) {
-        GN_TN2_LOAD(tile + 1);
-        typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const unsigned char* pa = &Ys[buf][ya_off + 16 * s * YP];
-            const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa));
-            const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * YP));
-            const s16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf16x8 af = __builtin_bit_cast(bf16x8, av);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const unsigned char* pb = &Xs[buf][xb_off + 16 * s * XP + nb * 64];
-                const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb));
-                const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * XP));
-                const s16x8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[nb], 0, 0, 0);
-            }
-            if (first_k) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb, 0, 0, 0);
-        }
-        GN_TN2_WRITE(buf ^ 1);
+    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+#define GN_TN2_MMA(buf_)                                                                             \
+    {                                                                                                \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                              \
+            const unsigned char* pa = &Ys[buf_][ya_off + 16 * s * YP];                               \
+            const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa));           \
+            const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * YP));  \
+            const s16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);              \
+            const bf16x8 af = __builtin_bit_cast(bf16x8, av);                                        \
+            _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) {                                       \
+                const unsigned char* pb = &Xs[buf_][xb_off + 16 * s * XP + nb * 64];                 \
+                const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb));       \
+                const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * XP)); \
+                const s16x8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);          \
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[nb], 0, 0, 0); \
+            }                                                                                        \
+            if (first_k) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb, 0, 0, 0);    \
+        }                                                                                            \
+    }
+    // two tiles per trip: set 0 holds tile+1 / tile+3, set 1 holds tile+2 / tile+4
+    for (; tile < tile_end; tile += 2) {
+        GN_TN2_MMA(0);
+        GN_TN2_WRITE(1, yr0, xr0);                  // tile + 1 (requested two tiles ago)
+        GN_TN2_LOAD(tile + 3, yr0, xr0);
+        __syncthreads();
+        if (tile + 1 < tile_end) GN_TN2_MMA(1);     // workgroup-uniform
+        GN_TN2_WRITE(0, yr1, xr1);                  // tile + 2
+        GN_TN2_LOAD(tile + 4, yr1, xr1);
         __syncthreads();
     }
 #undef GN_TN2_LOAD
 #undef GN_TN2_WRITE
+#undef GN_TN2_MMA
 
     float* out = slab + (long long)part * N1 * Ktot;
 #pragma unroll
