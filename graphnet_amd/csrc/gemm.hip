@@ -283,6 +283,13 @@ __device__ __forceinline__ void load_chunk8(Chunk8<__bf16>& r, const __bf16* row
     const u32x4 z = {0u, 0u, 0u, 0u};
     r.w = (rok && c < lim) ? w : z;
 }
+__device__ __forceinline__ void load_chunk8_raw(Chunk8<float>& r, const float* p) {
+    r.a = *reinterpret_cast<const f32x4*>(p);
+    r.b = *reinterpret_cast<const f32x4*>(p + 4);
+}
+__device__ __forceinline__ void load_chunk8_raw(Chunk8<__bf16>& r, const __bf16* p) { r.w = *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void zero_chunk8(Chunk8<float>& r) { r.a = (f32x4){0.f, 0.f, 0.f, 0.f}; r.b = r.a; }
+__device__ __forceinline__ void zero_chunk8(Chunk8<__bf16>& r) { r.w = (u32x4){0u, 0u, 0u, 0u}; }
 __device__ __forceinline__ u32x4 pack_chunk8(const Chunk8<float>& r) {
     u32x4 w;
     w[0] = pk_bf16(r.a[0], r.a[1]); w[1] = pk_bf16(r.a[2], r.a[3]);
@@ -292,6 +299,41 @@ __device__ __forceinline__ u32x4 pack_chunk8(const Chunk8<float>& r) {
 __device__ __forceinline__ u32x4 pack_chunk8(const Chunk8<__bf16>& r) { return r.w; }
 
 constexpr int TN2_ROWS = 64, TN2_N1 = 256, TN2_K = 128;
+typedef short s16x4_t_ __attribute__((ext_vector_type(4)));
+typedef short s16x8_t_ __attribute__((ext_vector_type(8)));
+struct Tn2Frags { s16x4_t_ a0, a1, b0[4], b1[4]; };
+__device__ __forceinline__ void tn2_read(Tn2Frags& f, const unsigned char* pa, const unsigned char* pb, int YP, int XP) {
+    typedef __attribute__((address_space(3))) s16x4_t_ lds_s16x4;
+    f.a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa));
+    f.a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * YP));
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        f.b0[nb] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + nb * 64));
+        f.b1[nb] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + nb * 64 + 4 * XP));
+    }
+}
+template <bool ONES>
+__device__ __forceinline__ void tn2_tile(const unsigned char* ya, const unsigned char* xb, f32x16 (&acc)[4], f32x16& accb) {
+    constexpr int YP = tr_pitch_g(256 * 2), XP = tr_pitch_g(128 * 2);
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    Tn2Frags f[2];
+    tn2_read(f[0], ya, xb, YP, XP);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s + 1 < 4) tn2_read(f[(s + 1) & 1], ya + 16 * (s + 1) * YP, xb + 16 * (s + 1) * XP, YP, XP);
+        const Tn2Frags& c = f[s & 1];
+        const bf16x8 af = __builtin_bit_cast(bf16x8, (s16x8_t_)__builtin_shufflevector(c.a0, c.a1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const s16x8_t_ bv = __builtin_shufflevector(c.b0[nb], c.b1[nb], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[nb], 0, 0, 0);
+        }
+        if constexpr (ONES) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);            // keep the next step's reads ahead of this step's MFMAs
+    }
+}
 template <typename DYT, typename XT>
 __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
     const DYT* __restrict__ dY, long long lddy, int N1, Segs x, int M, int nparts,
@@ -348,17 +390,38 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
     // Two register sets: the rows of tile t+2 are requested while tile t is multiplied (one tile of MFMAs is
     // ~1300 cycles, less than an HBM round trip under load: with a single set every iteration ended on the loads).
     const int srow = tid >> 3, sc = tid & 7;
-    Chunk8<DYT> yr0[4], yr1[4];
-    Chunk8<XT> xr0[2], xr1[2];
+    Chunk8<DYT> yr0[4], yr1[sizeof(DYT) == 2 && sizeof(XT) == 2 ? 4 : 1];
+    Chunk8<XT> xr0[2], xr1[sizeof(DYT) == 2 && sizeof(XT) == 2 ? 2 : 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { zero_chunk8(yr0[j]); if (j < (int)(sizeof(yr1) / sizeof(yr1[0]))) zero_chunk8(yr1[j]); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { zero_chunk8(xr0[j]); if (j < (int)(sizeof(xr1) / sizeof(xr1[0]))) zero_chunk8(xr1[j]); }
+    // Full tiles (every row < M; all but the last) take the fast path: running row pointers, chunk j at an immediate
+    // offset, no selects; a chunk that lies beyond N1 / the segment width (thread-constant) is never loaded, its
+    // registers stay zero.  The tail tile and the prefetches past the end use the clamped, select-based form.
+    bool yok[4], xok[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) yok[j] = n1_0 + (sc + 8 * j) * 8 < N1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xok[j] = kcol0 + (sc + 8 * j) * 8 < xw;
+    const DYT* ybase = dY + (long long)srow * lddy + n1_0 + sc * 8;
+    const XT* xbase = xp + (long long)srow * ldx + kcol0 + sc * 8;
 #define GN_TN2_LOAD(t_, yr, xr)                                                                      \
     {                                                                                                \
-        const int m__ = (t_) * TN2_ROWS + srow;                                                      \
-        const bool mok__ = (t_) < tile_end && m__ < M;                                               \
-        const long long ms__ = mok__ ? m__ : 0;                                                      \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
-            load_chunk8(yr[j], dY + ms__ * lddy, n1_0 + (sc + 8 * j) * 8, N1, mok__);                \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
-            load_chunk8(xr[j], xp + ms__ * ldx, kcol0 + (sc + 8 * j) * 8, xw, mok__);                \
+        if ((t_) < tile_end && ((t_) + 1) * TN2_ROWS <= M) {                 /* workgroup-uniform */  \
+            const DYT* yp__ = ybase + (long long)(t_) * TN2_ROWS * lddy;                             \
+            const XT* xp__ = xbase + (long long)(t_) * TN2_ROWS * ldx;                               \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) if (yok[j]) load_chunk8_raw(yr[j], yp__ + j * 64); \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) if (xok[j]) load_chunk8_raw(xr[j], xp__ + j * 64); \
+        } else {                                                                                     \
+            const int m__ = (t_) * TN2_ROWS + srow;                                                  \
+            const bool mok__ = (t_) < tile_end && m__ < M;                                           \
+            const long long ms__ = mok__ ? m__ : 0;                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
+                load_chunk8(yr[j], dY + ms__ * lddy, n1_0 + (sc + 8 * j) * 8, N1, mok__);            \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                            \
+                load_chunk8(xr[j], xp + ms__ * ldx, kcol0 + (sc + 8 * j) * 8, xw, mok__);            \
+        }                                                                                            \
     }
 #define GN_TN2_WRITE(buf_, yr, xr)                                                                   \
     {                                                                                                \
@@ -369,49 +432,42 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
     }
     // out-of-range float4s are read from a clamped (valid) address and zeroed: branch-free staging
 
+    // fp32 operands take twice the staging registers: one set (rows requested one tile ahead) for those
+    constexpr bool DEEP = sizeof(DYT) == 2 && sizeof(XT) == 2;
     GN_TN2_LOAD(tile, yr0, xr0);
     GN_TN2_WRITE(0, yr0, xr0);
     GN_TN2_LOAD(tile + 1, yr0, xr0);
-    GN_TN2_LOAD(tile + 2, yr1, xr1);
+    if constexpr (DEEP) GN_TN2_LOAD(tile + 2, yr1, xr1);
     __syncthreads();
 
     const int g4 = lane >> 4, li = lane & 15;
     const int tr_row = 8 * (g4 >> 1) + (li >> 2), tr_col = (16 * (g4 & 1) + 4 * (li & 3)) * 2;
     const int ya_off = tr_row * YP + wave * 64 + tr_col;     // A: n1 block = wave
     const int xb_off = tr_row * XP + tr_col;
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
-    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
-#define GN_TN2_MMA(buf_)                                                                             \
-    {                                                                                                \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                              \
-            const unsigned char* pa = &Ys[buf_][ya_off + 16 * s * YP];                               \
-            const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa));           \
-            const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * YP));  \
-            const s16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);              \
-            const bf16x8 af = __builtin_bit_cast(bf16x8, av);                                        \
-            _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) {                                       \
-                const unsigned char* pb = &Xs[buf_][xb_off + 16 * s * XP + nb * 64];                 \
-                const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb));       \
-                const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * XP)); \
-                const s16x8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);          \
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[nb], 0, 0, 0); \
-            }                                                                                        \
-            if (first_k) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb, 0, 0, 0);    \
-        }                                                                                            \
-    }
-    // two tiles per trip: set 0 holds tile+1 / tile+3, set 1 holds tile+2 / tile+4
-    for (; tile < tile_end; tile += 2) {
-        GN_TN2_MMA(0);
-        GN_TN2_WRITE(1, yr0, xr0);                  // tile + 1 (requested two tiles ago)
-        GN_TN2_LOAD(tile + 3, yr0, xr0);
-        __syncthreads();
-        if (tile + 1 < tile_end) GN_TN2_MMA(1);     // workgroup-uniform
-        GN_TN2_WRITE(0, yr1, xr1);                  // tile + 2
-        GN_TN2_LOAD(tile + 4, yr1, xr1);
-        __syncthreads();
+    // one 64-row tile: the transposed fragments of k-step s+1 are requested before the MFMAs of k-step s
+#define GN_TN2_MMA(buf_) { if (first_k) tn2_tile<true>(&Ys[buf_][ya_off], &Xs[buf_][xb_off], acc, accb); \
+                           else tn2_tile<false>(&Ys[buf_][ya_off], &Xs[buf_][xb_off], acc, accb); }
+    if constexpr (DEEP) {
+        // two tiles per trip: set 0 holds tile+1 / tile+3, set 1 holds tile+2 / tile+4
+        for (; tile < tile_end; tile += 2) {
+            GN_TN2_MMA(0);
+            GN_TN2_WRITE(1, yr0, xr0);                  // tile + 1 (requested two tiles ago)
+            GN_TN2_LOAD(tile + 3, yr0, xr0);
+            __syncthreads();
+            if (tile + 1 < tile_end) GN_TN2_MMA(1);     // workgroup-uniform
+            GN_TN2_WRITE(0, yr1, xr1);                  // tile + 2
+            GN_TN2_LOAD(tile + 4, yr1, xr1);
+            __syncthreads();
+        }
+    } else {
+        int buf = 0;
+        for (; tile < tile_end; ++tile, buf ^= 1) {
+            if (buf == 0) { GN_TN2_MMA(0); GN_TN2_WRITE(1, yr0, xr0); }
+            else { GN_TN2_MMA(1); GN_TN2_WRITE(0, yr0, xr0); }
+            GN_TN2_LOAD(tile + 2, yr0, xr0);
+            __syncthreads();
+        }
     }
 #undef GN_TN2_LOAD
 #undef GN_TN2_WRITE
