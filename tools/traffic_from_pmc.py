@@ -6,7 +6,7 @@ usage: traffic_from_pmc.py fetch.db write.db out.json [events_per_gpu]"""
 import json, sqlite3, sys
 EVENTS = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 GROUPS = {  # op group of bench.py -> substring of its dominant kernel
-    "edgeconv_fwd": "edge_fwd_v2_kernelILi22", "edgeconv_bwd": "edge_bwd_v2_kernelILi11",
+    "edgeconv_fwd": "edge_fwd_ws_kernelILi22", "edgeconv_bwd": "edge_bwd_v2_kernelILi11",
     "edgeconv_dw2": "edge_dw2_v2_kernelILi11", "edgeconv_dq_gather": "dq_gather_kernel",
     "linear_fwd": "gemm_nt_v2_kernelILi16ELi11", "linear_wgrad": "gemm_tn_v2_kernel", "knn_graph": "knn_kernel",
 }
