@@ -367,7 +367,7 @@ def _edgeconv_case(oracle, k=8, F=32, H1=336, H2=256, n_events=14, seed=6, dup=T
 
 
 @pytest.mark.parametrize("name,mode,tol", MODES)
-@pytest.mark.parametrize("k,F,H1,H2", [(8, 32, 336, 256), (8, 256, 336, 256), (16, 64, 128, 256), (5, 32, 100, 96)])
+@pytest.mark.parametrize("k,F,H1,H2", [(8, 32, 336, 256), (8, 256, 336, 256), (16, 64, 128, 256), (5, 32, 100, 96), (8, 32, 344, 256)])
 def test_edgeconv_forward(oracle, name, mode, tol, k, F, H1, H2):
     from graphnet_amd import ops
     b, x3, x, mlp, ei = _edgeconv_case(oracle, k=k, F=F, H1=H1, H2=H2)
@@ -384,7 +384,7 @@ def test_edgeconv_forward(oracle, name, mode, tol, k, F, H1, H2):
     bpq = torch.zeros(2 * H1p, device=DEV); bpq[:H1] = b1
     PQ = ops.linear_fwd(mode, [(x.to(DEV), F)], ops.pack_weight(Wpq, [F], dt, ops.gemm_kunit(mode)), 2 * H1p, bias=bpq, out_lowp=(mode == 1))
     out, _mask, coords = ops.edgeconv_fwd(mode, t, PQ, H1p, ops.pack_weight(W2, [H1], dt), b2, H2,
-                                          coord_cols=[0, 1, 2, 5])
+                                          coord_cols=[0, 1, 2, 5], H1=H1)
     assert out.dtype == ops.act_dtype(mode)
     assert rel_err(out, ref) < tol, name
     # fp32 copy of the k-NN coordinate columns: the unrounded values of the same result
@@ -558,8 +558,9 @@ def test_persistent_kernels_match_generic_kernels(oracle):
     from graphnet_amd import ops
     mode, dt = 1, torch.bfloat16
     # k <= 8 -> 8 slots per centre (uint8 slot masks), 9 <= k <= 16 -> 16 slots (uint16 masks)
+    # H1 = 336: the contraction stops after 21 of the 22 k-steps of the padded layout; 340: real columns in the last one
     for (kk, F, H1, H2, n_events) in ((8, 256, 336, 256, 60), (8, 32, 128, 256, 20), (16, 256, 336, 256, 40),
-                                      (11, 32, 128, 256, 20)):
+                                      (11, 32, 128, 256, 20), (8, 64, 340, 256, 30), (16, 64, 348, 256, 20)):
         b, x3, x, mlp, ei = _edgeconv_case(oracle, k=kk, F=F, H1=H1, H2=H2, n_events=n_events, seed=12)
         ptr32, batch32 = _csr(b)
         g = ops.knn_graph(x3.to(DEV), [0, 1, 2], batch32, ptr32, kk)
@@ -577,7 +578,7 @@ def test_persistent_kernels_match_generic_kernels(oracle):
         res = {}
         for tag, flag in (("v2", "0"), ("v1", "1")):
             os.environ["GN_DISABLE_V2"] = flag
-            out, saved = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2)
+            out, saved = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2, H1=H1)
             dW2, db2 = ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, gout, saved)
             dPQ = torch.zeros(N, 2 * H1p, dtype=dt, device=DEV)
             dpre = torch.zeros(g.rows, H1p, dtype=dt, device=DEV)
