@@ -656,7 +656,7 @@ hipError_t launch_edge_bwd_v2(const EdgeGraph& g, int H1p, int H2, const void* g
                               void* dpre, void* dP, long long ldp, int num_cus, hipStream_t st);
 bool edge_v2_shape_ok(int K, int H1p, int H2);
 int edge_dw2_v2_parts(int N, int K, int H1p, int num_cus);
-constexpr int DW2_OVF_SPLITS = 8;
+constexpr int DW2_OVF_SPLITS = 40;    // x 6 column tiles = 240 workgroups: tie-heavy graphs (many pulses per DOM) have ~N overflow rows
 
 int device_cus() {
     static int cus = 0;

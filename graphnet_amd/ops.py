@@ -126,9 +126,12 @@ class NeighbourTable:
         L = _lib.lib()
         N, dev = self.N, self.nbr.device
         ev_ptr = getattr(self, "event_ptr", None)
-        if ev_ptr is not None and (self.ovf is None or getattr(self, "ovf_pos", None) is not None):
-            # edges never leave an event (built by knn_graph): per-event build with LDS counters
-            B = int(ev_ptr.shape[0]) - 1
+        B = int(ev_ptr.shape[0]) - 1 if ev_ptr is not None else 0
+        # edges never leave an event (built by knn_graph): per-event build with LDS counters, one workgroup per
+        # event - only when there are enough events to fill the chip (a handful of 10^4-pulse events, BASELINE
+        # configs[4], would run on a handful of CUs: 5.4 ms instead of 0.4 ms for the global build)
+        if ev_ptr is not None and (self.ovf is None or getattr(self, "ovf_pos", None) is not None) \
+                and B >= 64 and N <= 2048 * B:
             rev_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
             rev_rows = torch.empty(max(N * self.K + N, 1), dtype=torch.int32, device=dev)
             ev = torch.empty(2 * (B + 1), dtype=torch.int32, device=dev)
