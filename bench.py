@@ -330,6 +330,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_events, args.cpu_steps)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()                  # rank 0 is still measuring its yardsticks: leave together
         dist.destroy_process_group()
 
 
