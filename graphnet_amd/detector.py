@@ -6,7 +6,8 @@ column by column, ``KeyError`` for an unknown feature name) and the scaling cons
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Sequence, Tuple
+import os
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor
@@ -45,6 +46,54 @@ class Detector(Model):
     xyz: List[str] = []
     string_id_column = "string"
     sensor_id_column = "sensor_id"
+    # parquet with the xyz / string / sensor-id columns (detector.py:33-46): (experiment directory, file name) below
+    # the directory named by $GRAPHNET_AMD_GEOMETRY_TABLES (the reference's data/geometry_tables), or an explicit path
+    geometry_table_file: Optional[Tuple[str, str]] = None
+
+    @property
+    def geometry_table_path(self) -> Optional[str]:
+        explicit = getattr(self, "_geometry_table_path", None)
+        if explicit:
+            return explicit
+        root = os.environ.get("GRAPHNET_AMD_GEOMETRY_TABLES")
+        if root and self.geometry_table_file:
+            return os.path.join(root, *self.geometry_table_file)
+        return None
+
+    @geometry_table_path.setter
+    def geometry_table_path(self, path: Optional[str]) -> None:
+        self._geometry_table_path = path
+        self._geometry_table = None
+
+    @property
+    def geometry_table(self):
+        """Sensor table (pandas), read once from ``geometry_table_path``; may also be assigned
+        (``detector.geometry_table = frame``) where the reference's data directory is not installed."""
+        if getattr(self, "_geometry_table", None) is None:
+            path = self.geometry_table_path
+            if not path:
+                raise AttributeError(f"{self.__class__.__name__}: no geometry table - set $GRAPHNET_AMD_GEOMETRY_TABLES, "
+                                     "detector.geometry_table_path or detector.geometry_table = <DataFrame> before "
+                                     "using sensor / string masks or inactive sensors")
+            import pandas as pd
+            self._geometry_table = pd.read_parquet(path)
+        return self._geometry_table
+
+    @geometry_table.setter
+    def geometry_table(self, frame: Any) -> None:
+        self._geometry_table = frame
+
+    @property
+    def sensor_position_names(self) -> List[str]:
+        return list(self.xyz)
+
+    @property
+    def sensor_index_name(self) -> str:
+        return self.sensor_id_column
+
+    @property
+    def string_index_name(self) -> str:
+        return self.string_id_column
 
     def feature_ops(self) -> Dict[str, List[Op]]:
         """feature name -> program (``[]`` = identity)."""
@@ -74,6 +123,7 @@ class Detector(Model):
 
 class IceCube86(Detector):
     xyz = ["dom_x", "dom_y", "dom_z"]
+    geometry_table_file = ("icecube", "icecube86.parquet")
 
     def feature_ops(self):
         xyz = [("div", 500.0)]
@@ -95,6 +145,7 @@ class IceCubeDeepCore(IceCube86):
 
 class IceCubeUpgrade(Detector):
     xyz = ["dom_x", "dom_y", "dom_z"]
+    geometry_table_file = ("icecube", "icecube_upgrade.parquet")
 
     def feature_ops(self):
         return {
@@ -114,6 +165,7 @@ class IceCubeUpgrade(Detector):
 
 class ORCA150SuperDense(Detector):
     xyz = ["sensor_pos_x", "sensor_pos_y", "sensor_pos_z"]
+    geometry_table_file = ("prometheus", "orca_150.parquet")
     string_id_column = "sensor_string_id"
 
     def feature_ops(self):

@@ -11,7 +11,7 @@ There is no CPU k-NN in this package.
 """
 from __future__ import annotations
 
-from typing import Any, Callable, Dict, List, Optional, Union
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -79,8 +79,10 @@ class KNNEdges(EdgeDefinition):
 
 
 class GraphDefinition(Model):
-    """numpy pulses -> ``Data`` (``graph_definition.py:27-248``; mask / inactive-sensor options
-    of the reference are data-side conveniences outside the hot path and not mirrored)."""
+    """numpy pulses -> ``Data`` (``models/graphs/graph_definition.py:27-465``): optional inactive sensors, sensor /
+    string masks and Gaussian perturbation on the raw array, then tensor -> detector standardisation -> node
+    definition -> optional sort -> ``n_pulses`` -> edges -> loss weight, truth / custom labels (optionally repeated
+    per node) and the node features as separate attributes."""
 
     def __init__(
         self,
@@ -91,23 +93,42 @@ class GraphDefinition(Model):
         dtype: Optional[torch.dtype] = torch.float,
         perturbation_dict: Optional[Dict[str, float]] = None,
         seed: Optional[Union[int, Generator]] = None,
+        add_inactive_sensors: bool = False,
+        sensor_mask: Optional[List[int]] = None,
+        string_mask: Optional[List[int]] = None,
         sort_by: Optional[str] = None,
+        repeat_labels: bool = False,
     ):
         super().__init__()
         self._detector = detector
         self._node_definition = node_definition or NodesAsPulses()
         self._edge_definition = edge_definition
         self._perturbation_dict = perturbation_dict
-        self._sort_by = None
+        self._add_inactive_sensors = add_inactive_sensors
+        self._repeat_labels = repeat_labels
+        # one of the two masks at most; a string mask becomes the list of sensor ids on those strings
+        assert sensor_mask is None or string_mask is None, \
+            "Got arguments for both `sensor_mask` and `string_mask`. Please specify only one."
+        if string_mask is not None:
+            table = detector.geometry_table
+            on_string = table[detector.string_index_name].isin(string_mask)
+            sensor_mask = np.asarray(table.loc[on_string, detector.sensor_index_name]).tolist()
+        self._sensor_mask, self._string_mask = sensor_mask, string_mask
         if input_feature_names is None:
             input_feature_names = list(detector.feature_map().keys())
         self._input_feature_names = list(input_feature_names)
-        if sort_by is not None:
-            self._sort_by = self._input_feature_names.index(sort_by)
         self._node_definition.set_output_feature_names(self._input_feature_names)
+        self.output_feature_names = list(getattr(self._node_definition, "_output_feature_names",
+                                                 self._input_feature_names))
+        self._sort_by = None
+        if sort_by is not None:
+            assert isinstance(sort_by, str)
+            self._sort_by = self.output_feature_names.index(sort_by)       # ValueError if it is not a node feature
         self.nb_inputs = len(self._input_feature_names)
         self.nb_outputs = self._node_definition.nb_outputs
         self.dtype = dtype
+        if isinstance(self._perturbation_dict, dict):
+            self._perturbation_cols = [self._input_feature_names.index(k) for k in self._perturbation_dict]
         if isinstance(seed, Generator):
             self.rng = seed
         elif seed is None:
@@ -116,6 +137,36 @@ class GraphDefinition(Model):
             self.rng = default_rng(seed)
         else:
             raise ValueError("Invalid seed. Must be an int or a numpy Generator.")
+        self._sensor_rows: Optional[Dict[Tuple[float, ...], int]] = None
+
+    # ---- geometry-table helpers (graph_definition.py:263-325) ------------------------------------------------
+    def _geometry_rows(self, input_features: np.ndarray, input_feature_names: List[str]) -> np.ndarray:
+        """Row of the detector's geometry table for every pulse, looked up by its xyz position (KeyError for a
+        position that is not in the table, as the reference's ``.loc`` lookup)."""
+        det = self._detector
+        if self._sensor_rows is None:
+            pos = det.geometry_table.reset_index()[det.sensor_position_names].to_numpy(dtype=np.float64)
+            self._sensor_rows = {tuple(row): i for i, row in enumerate(pos.tolist())}
+        cols = [input_feature_names.index(f) for f in det.sensor_position_names]
+        keys = np.asarray(input_features[:, cols], dtype=np.float64).tolist()
+        return np.fromiter((self._sensor_rows[tuple(k)] for k in keys), dtype=np.int64, count=len(keys))
+
+    def _attach_inactive_sensors(self, input_features: np.ndarray, input_feature_names: List[str]) -> np.ndarray:
+        """Append one padded row per sensor of the geometry table that recorded no pulse."""
+        table = self._detector.geometry_table.reset_index()
+        hit = np.zeros(len(table), dtype=bool)
+        hit[self._geometry_rows(input_features, input_feature_names)] = True
+        missing = [f for f in input_feature_names if f not in table.columns]
+        if missing:
+            raise KeyError(f"geometry table lacks the columns {missing} needed to pad inactive sensors")
+        inactive = table.loc[~hit, input_feature_names].to_numpy()
+        return np.concatenate([input_features, inactive], axis=0)
+
+    def _mask_sensors(self, input_features: np.ndarray, input_feature_names: List[str]) -> np.ndarray:
+        """Drop the pulses recorded by a masked sensor."""
+        table = self._detector.geometry_table.reset_index()
+        ids = table[self._detector.sensor_index_name].to_numpy()[self._geometry_rows(input_features, input_feature_names)]
+        return input_features[~np.isin(ids, np.asarray(self._sensor_mask)), :]
 
     def _validate_input(self, input_features: np.ndarray, input_feature_names: List[str]) -> None:
         assert input_features.shape[1] == len(input_feature_names)
@@ -125,33 +176,68 @@ class GraphDefinition(Model):
 
     def _perturb_input(self, input_features: np.ndarray) -> np.ndarray:
         if isinstance(self._perturbation_dict, dict):
-            cols = [self._input_feature_names.index(k) for k in self._perturbation_dict]
-            sig = np.array(list(self._perturbation_dict.values()))
-            input_features[:, cols] = self.rng.normal(loc=input_features[:, cols], scale=sig)
+            sig = np.array(list(self._perturbation_dict.values()), dtype=float)
+            input_features[:, self._perturbation_cols] = self.rng.normal(
+                loc=input_features[:, self._perturbation_cols], scale=sig)
         return input_features
+
+    def _add_loss_weights(self, graph: Data, loss_weight_column: Optional[str], loss_weight: Optional[float],
+                          loss_weight_default_value: Optional[float]) -> Data:
+        """``graph[loss_weight_column] = loss_weight`` as a ``[1, 1]`` tensor; a negative weight means "missing"
+        and takes the default value (``graph_definition.py:363-398``; the reference reads the default from an
+        attribute it never sets - the argument is used here)."""
+        if loss_weight is not None and loss_weight_column is not None:
+            if loss_weight < 0:
+                if loss_weight_default_value is None:
+                    raise ValueError(f"At least one event is missing an entry in {loss_weight_column} "
+                                     "but loss_weight_default_value is None.")
+                loss_weight = loss_weight_default_value
+            graph[loss_weight_column] = torch.tensor(loss_weight, dtype=self.dtype).reshape(-1, 1)
+        return graph
+
+    def _label(self, value: Any, graph: Data) -> torch.Tensor:
+        label = value if isinstance(value, torch.Tensor) else torch.tensor(value)
+        return label.repeat(graph.x.shape[0], 1) if self._repeat_labels else label
 
     def forward(self, input_features: np.ndarray, input_feature_names: List[str],
                 truth_dicts: Optional[List[Dict[str, Any]]] = None,
                 custom_label_functions: Optional[Dict[str, Callable[..., Any]]] = None,
-                **_unused: Any) -> Data:
+                loss_weight_column: Optional[str] = None, loss_weight: Optional[float] = None,
+                loss_weight_default_value: Optional[float] = None, data_path: Optional[str] = None) -> Data:
         self._validate_input(input_features, input_feature_names)
+        if self._add_inactive_sensors:
+            input_features = self._attach_inactive_sensors(input_features, input_feature_names)
+        if self._sensor_mask is not None:
+            input_features = self._mask_sensors(input_features, input_feature_names)
         input_features = self._perturb_input(input_features)
         x = torch.tensor(input_features, dtype=self.dtype)
         x = self._detector(x, input_feature_names)
-        graph, _names = self._node_definition(x)
+        graph, node_feature_names = self._node_definition(x)
         if self._sort_by is not None:
             graph.x = graph.x[graph.x[:, self._sort_by].sort()[1]]
         graph.x = graph.x.type(self.dtype)
         graph.n_pulses = torch.tensor(len(input_features), dtype=torch.int32)
         if self._edge_definition is not None:
             graph = self._edge_definition(graph)
+        if data_path is not None:
+            graph["dataset_path"] = data_path
+        graph = self._add_loss_weights(graph, loss_weight_column, loss_weight, loss_weight_default_value)
         if truth_dicts is not None:
             for td in truth_dicts:
                 for k, v in td.items():
-                    graph[k] = torch.tensor(v)
+                    try:
+                        graph[k] = self._label(v, graph)
+                    except (TypeError, ValueError, RuntimeError):      # e.g. a string: not attached (as the reference)
+                        pass
         if custom_label_functions is not None:
             for k, fn in custom_label_functions.items():
-                graph[k] = fn(graph)
+                graph[k] = self._label(fn(graph), graph)
+        # the node features once more as separate attributes ('x' is reserved for the feature matrix)
+        names = list(node_feature_names) if node_feature_names is not None else list(self.output_feature_names)
+        graph["features"] = names
+        for index, feature in enumerate(names):
+            if feature != "x":
+                graph[feature] = graph.x[:, index].detach()
         graph["graph_definition"] = self.__class__.__name__
         return graph
 

@@ -389,3 +389,87 @@ def test_flat_buffer_batch_equals_per_event_path():
     assert torch.equal(flat.n_pulses, per_event.n_pulses)
     assert torch.allclose(flat.energy.float(), per_event.energy.float())
     assert flat.num_graphs == 5 and flat.knn_k == 8 and flat.knn_columns == [0, 1, 2]
+
+
+# ---- GraphDefinition options on the raw pulse array (graph_definition.py:148-465) --------------------------
+def _icecube86_table():
+    """The IceCube-86 sensor table of the reference's data directory, as committed in tests/golden (5407 sensors)."""
+    import os
+    import pandas as pd
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "icecube86_geometry.npz"))
+    t = pd.DataFrame(d["table"], columns=["dom_x", "dom_y", "dom_z", "rde", "pmt_area"])
+    t["string"] = d["string"].astype(np.int64)
+    t["sensor_id"] = np.arange(len(t), dtype=np.int64)
+    return t
+
+
+def _pulses_on_sensors(table, sensor_ids, rng):
+    """Raw pulses (7 IceCube-86 features) recorded by the given sensors, in the given order."""
+    rows = table.iloc[sensor_ids]
+    n = len(rows)
+    return np.stack([rows["dom_x"].to_numpy(), rows["dom_y"].to_numpy(), rows["dom_z"].to_numpy(),
+                     1e4 + rng.uniform(0, 2e3, n), rng.lognormal(0, 0.5, n),
+                     rows["rde"].to_numpy(), rows["pmt_area"].to_numpy()], axis=1)
+
+
+def test_graph_definition_sensor_and_string_masks():
+    table = _icecube86_table()
+    rng = np.random.default_rng(3)
+    ids = np.array([10, 11, 11, 500, 2000, 2000, 2000, 4000, 5406])
+    raw = _pulses_on_sensors(table, ids, rng)
+    det = g.IceCube86()
+    det.geometry_table = table
+    gd = g.GraphDefinition(det, input_feature_names=FEATURES_ICECUBE86, sensor_mask=[11, 2000])
+    out = gd(raw.copy(), FEATURES_ICECUBE86)
+    keep = ~np.isin(ids, [11, 2000])
+    ref = g.GraphDefinition(g.IceCube86(), input_feature_names=FEATURES_ICECUBE86)(raw[keep].copy(), FEATURES_ICECUBE86)
+    assert int(out.n_pulses) == int(keep.sum()) == 4
+    assert torch.equal(out.x, ref.x)
+    # a string mask is the sensor mask of every sensor on those strings
+    strings = sorted(set(table["string"].to_numpy()[[11, 2000]].tolist()))
+    det2 = g.IceCube86()
+    det2.geometry_table = table
+    out2 = g.GraphDefinition(det2, input_feature_names=FEATURES_ICECUBE86, string_mask=strings)(raw.copy(), FEATURES_ICECUBE86)
+    keep2 = ~np.isin(table["string"].to_numpy()[ids], strings)
+    assert int(out2.n_pulses) == int(keep2.sum())
+    with pytest.raises(AssertionError):
+        g.GraphDefinition(det, sensor_mask=[1], string_mask=[1])
+    # a position that is not in the table cannot be looked up
+    bad = raw.copy(); bad[0, 0] += 0.123
+    with pytest.raises(KeyError):
+        gd(bad, FEATURES_ICECUBE86)
+    # no table: a clear error instead of a silent no-op
+    with pytest.raises(AttributeError):
+        g.GraphDefinition(g.IceCube86(), string_mask=[1])
+
+
+def test_graph_definition_inactive_sensors_labels_and_attributes():
+    table = _icecube86_table()
+    rng = np.random.default_rng(4)
+    ids = np.array([7, 7, 300, 301, 5000])
+    names = ["dom_x", "dom_y", "dom_z", "rde", "pmt_area"]          # columns the geometry table can pad
+    raw = _pulses_on_sensors(table, ids, rng)[:, [0, 1, 2, 5, 6]]
+    det = g.IceCube86()
+    det.geometry_table = table
+    gd = g.GraphDefinition(det, input_feature_names=names, add_inactive_sensors=True, sort_by="dom_z", repeat_labels=True)
+    out = gd(raw.copy(), names, truth_dicts=[{"energy": 12.5, "event_no": 3, "tag": "numu"}],
+             custom_label_functions={"twice": lambda gr: gr["energy"][:1] * 2},
+             loss_weight_column="w", loss_weight=-1.0, loss_weight_default_value=0.25, data_path="/some/file.db")
+    n_unique = len(set(ids.tolist()))
+    n_rows = len(ids) + len(table) - n_unique                        # every silent sensor appended once
+    assert int(out.n_pulses) == n_rows and out.x.shape == (n_rows, 5)
+    z = out.x[:, 2]
+    assert bool((z[1:] >= z[:-1]).all())                             # sort_by
+    assert out["energy"].shape == (n_rows, 1) and float(out["energy"][0, 0]) == 12.5   # repeat_labels
+    assert out["twice"].shape[0] == n_rows and float(out["twice"][0, 0]) == 25.0
+    assert "tag" not in out                                          # strings are not attached
+    assert out["w"].shape == (1, 1) and float(out["w"]) == 0.25      # missing weight -> default
+    assert out["dataset_path"] == "/some/file.db"
+    assert out["features"] == names and torch.allclose(out["rde"], out.x[:, 3], rtol=0, atol=0, equal_nan=True)
+    assert out["graph_definition"] == "GraphDefinition"
+    with pytest.raises(ValueError):
+        gd(raw.copy(), names, loss_weight_column="w", loss_weight=-1.0)
+    # dom_time is not a column of the geometry table: inactive sensors cannot be padded for it
+    gd7 = g.GraphDefinition(det, input_feature_names=FEATURES_ICECUBE86, add_inactive_sensors=True)
+    with pytest.raises(KeyError):
+        gd7(_pulses_on_sensors(table, ids, rng), FEATURES_ICECUBE86)
