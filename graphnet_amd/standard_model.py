@@ -131,7 +131,8 @@ class VonMisesFisher3DLoss(VonMisesFisherLoss):
 
 
 class Task(Model):
-    """``models/task/task.py:22-222`` (transform handling reduced to what the path uses)."""
+    """``models/task/task.py:22-222``: labels, training / inference transforms (validated as an inverse pair),
+    optional per-event loss weight column."""
 
     nb_inputs: int = 1
     default_target_labels: List[str] = []
@@ -165,11 +166,33 @@ class Task(Model):
         if (transform_target is not None) != (transform_inference is not None):
             raise AssertionError("Please specify both `transform_inference` and `transform_target`")
         if transform_target is not None:
+            self._check_inverse_pair(transform_target, transform_inference, transform_support)
             self._transform_target = transform_target
             self._transform_prediction_inference = transform_inference
         elif transform_prediction_and_target is not None:
             self._transform_prediction_training = transform_prediction_and_target
             self._transform_target = transform_prediction_and_target
+
+    @staticmethod
+    def _check_inverse_pair(transform_target: Callable, transform_inference: Callable,
+                            transform_support: Optional[tuple]) -> None:
+        """``task.py:145-209``: the inference transform must undo the target transform wherever the round trip is
+        finite - on 10 points of ``transform_support = (min, max)`` or, without one, on +-10^-6 .. 10^6 and 0.
+        Transforms that index into their argument cannot be probed with a 1-d vector and are not checked."""
+        if transform_support is not None:
+            assert len(transform_support) == 2, "Please specify min and max for transformation support."
+            probe = torch.from_numpy(np.linspace(transform_support[0], transform_support[1], 10))
+        else:
+            mag = np.logspace(-6, 6, 13)
+            probe = torch.from_numpy(np.concatenate([-mag[::-1], [0.0], mag]))
+        try:
+            back = transform_inference(transform_target(probe).unsqueeze(-1)).squeeze(-1)
+        except IndexError:
+            return
+        ok = torch.isfinite(back)
+        assert torch.allclose(back[ok], probe[ok]), (
+            "The provided transforms for targets during training and predictions during inference are not "
+            "inverse. Please adjust transformation functions or support.")
 
     def inference(self) -> None:
         self._inference = True

@@ -473,3 +473,23 @@ def test_graph_definition_inactive_sensors_labels_and_attributes():
     gd7 = g.GraphDefinition(det, input_feature_names=FEATURES_ICECUBE86, add_inactive_sensors=True)
     with pytest.raises(KeyError):
         gd7(_pulses_on_sensors(table, ids, rng), FEATURES_ICECUBE86)
+
+
+def test_task_transform_pair_is_validated():
+    """task.py:145-209: transform_inference must invert transform_target on the probe points."""
+    kw = dict(hidden_size=8, loss_function=g.LogCoshLoss())
+    g.EnergyReconstruction(transform_target=torch.log10, transform_inference=lambda x: torch.pow(10, x),
+                           transform_support=(1.0, 1e6), **kw)
+    g.EnergyReconstruction(transform_target=torch.log10, transform_inference=lambda x: torch.pow(10, x), **kw)  # non-finite points skipped
+    with pytest.raises(AssertionError):
+        g.EnergyReconstruction(transform_target=torch.log10, transform_inference=torch.exp, transform_support=(1.0, 1e3), **kw)
+    with pytest.raises(AssertionError):
+        g.EnergyReconstruction(transform_target=torch.log10, transform_inference=torch.exp, transform_support=(1.0,), **kw)
+    with pytest.raises(AssertionError):
+        g.EnergyReconstruction(transform_target=torch.log10, transform_prediction_and_target=torch.log10,
+                               transform_inference=torch.exp, **kw)
+    t = g.EnergyReconstruction(transform_target=torch.log10, transform_inference=lambda x: torch.pow(10, x), **kw)
+    x = torch.randn(5, 8)
+    train_out = t(x)
+    t.inference()
+    assert torch.allclose(t(x), torch.pow(10, train_out))
