@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph (experimental) instead of eager launches")
-    ap.add_argument("--profile-steps", type=int, default=3, help="eager steps with per-op HIP events (roofline)")
+    ap.add_argument("--profile-steps", type=int, default=10, help="eager steps with per-op HIP events (roofline)")
     ap.add_argument("--extra-events", type=int, default=1024,
                     help="also report events/s at this many events per GPU (SURVEY 8d: B in {256,1024,4096}); 0 = skip")
     ap.add_argument("--cpu-events", type=int, default=64)
@@ -219,6 +219,7 @@ def main():
         eager_step()
     fence()
     timers = ops.timer_summary()
+    detail = ops.timer_summary(detail=True)
     ops.enable_timers(False)
     prof_steps = max(1, args.profile_steps)
     # second batch size (same model, same step), reported beside the headline value
@@ -289,9 +290,22 @@ def main():
         name, (launches, ms) = dom
         per_launch_ms = ms / max(launches, 1)
         lps = launches / prof_steps
+        kernel_shape = None
         if name in flops:
             bound, unit = "mfma", "TFLOP/s"
-            achieved = flops[name] / lps / (per_launch_ms * 1e-3) / 1e12
+            # the group mixes layer shapes (conv 1 is 128 wide, conv 2-4 are 336 wide): price the ONE kernel shape
+            # that takes the most time with its own contraction, launch by launch - this is the duration a
+            # rocprofv3 kernel trace reports for that kernel
+            shapes = {k: v for k, v in detail.items() if k.startswith(name + "[")}
+            if shapes:
+                kernel_shape, (launches, ms) = max(shapes.items(), key=lambda kv: kv[1][1])
+                h1p, h2 = (int(v) for v in kernel_shape[len(name) + 1:-1].split("x"))
+                h1 = next(h for _, h, _ in conv if (h + 31) // 32 * 32 == h1p)
+                per_launch_ms = ms / max(launches, 1)
+                lps = launches / prof_steps
+                achieved = 2 * E * h1 * h2 / (per_launch_ms * 1e-3) / 1e12
+            else:
+                achieved = flops[name] / lps / (per_launch_ms * 1e-3) / 1e12
         else:
             bound, unit, peak = "hbm", "GB/s", 8000.0
             achieved = hbm_bytes.get(name, 0.0) / lps / (per_launch_ms * 1e-3) / 1e9
@@ -313,7 +327,7 @@ def main():
                                    "(~150/event, 7 features), k=8, fwd+bwd+Adam",
                        "events_per_gpu": args.events, "pulses_per_gpu": n_nodes, "edges_per_layer": n_edges,
                        "parallelism": f"dp{world} (event shards, one flat RCCL all-reduce)"},
-            "roofline": {"bound": bound, "kernel": name, "achieved": achieved, "peak": peak, "unit": unit,
+            "roofline": {"bound": bound, "kernel": kernel_shape or name, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic,
                          "launch_ms": per_launch_ms, "launches_per_step": lps},
             "group_tflops": {k: flops[k] / (timers[k][1] / prof_steps * 1e-3) / 1e12 for k in flops if k in timers},

@@ -31,8 +31,11 @@ def enable_timers(on: bool = True) -> None:
 
 
 class _timed:
-    def __init__(self, name: str):
-        self.name = name
+    """``detail``: a second key (op + shape) under which the same event pair is also listed, so that a caller can
+    price ONE kernel shape (bench.py's roofline) instead of the whole op group."""
+
+    def __init__(self, name: str, detail: Optional[str] = None):
+        self.name, self.detail = name, detail
 
     def __enter__(self):
         if _TIMERS is not None:
@@ -44,13 +47,17 @@ class _timed:
         if _TIMERS is not None:
             self.ev[1].record()
             _TIMERS.setdefault(self.name, []).append(self.ev)
+            if self.detail is not None:
+                _TIMERS.setdefault("@" + self.detail, []).append(self.ev)
         return False
 
 
-def timer_summary() -> dict:
-    """name -> (launches, total milliseconds); synchronises."""
+def timer_summary(detail: bool = False) -> dict:
+    """name -> (launches, total milliseconds); synchronises.  ``detail=True``: the per-shape entries instead
+    (``"edgeconv_dw2[352x256]"`` = H1p x H2)."""
     torch.cuda.synchronize()
-    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (_TIMERS or {}).items()}
+    return {(k[1:] if detail else k): (len(v), sum(a.elapsed_time(b) for a, b in v))
+            for k, v in (_TIMERS or {}).items() if k.startswith("@") == detail}
 
 
 def mode_dtype(mode: int) -> torch.dtype:
@@ -420,7 +427,7 @@ def edgeconv_fwd(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, W2p: Tensor
             raise ValueError("at most 8 coordinate columns")
         coords = torch.zeros((max(N, 1), 8), dtype=torch.float32, device=PQ.device)
         cc = (ctypes.c_int32 * max(nc, 1))(*[int(c) for c in coord_cols])
-    with _timed("edgeconv_fwd"):
+    with _timed("edgeconv_fwd", f"edgeconv_fwd[{H1p}x{H2}]"):
         _lib.check(_lib.lib().gn_edgeconv_fwd(mode, *g.c_args(), _p(PQ), H1p, H1p if H1 is None else int(H1), _p(W2p), _p(b2), H2, _p(out),
                                               _rows(out, "out"), _p(coords),
                                               None if cc is None else ctypes.cast(cc, ctypes.c_void_p), nc,
@@ -433,7 +440,7 @@ def edgeconv_fwd(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, W2p: Tensor
 def edgeconv_bwd(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, H2: int, gout: Tensor, mask: Tensor,
                  W2Tp: Tensor, dpre: Tensor, dP: Tensor) -> None:
     _need(gout, act_dtype(mode), "gout"); _need(dP, act_dtype(mode), "dP")
-    with _timed("edgeconv_bwd"):
+    with _timed("edgeconv_bwd", f"edgeconv_bwd[{H1p}x{H2}]"):
         _lib.check(_lib.lib().gn_edgeconv_bwd(mode, *g.c_args(), _p(PQ), H1p, H2, _p(gout), _rows(gout, "gout"),
                                               _p(mask), _p(W2Tp), int(W2Tp.shape[1]), _p(dpre), _p(dP),
                                               _rows(dP, "dP"), _st()))
@@ -448,7 +455,7 @@ def edgeconv_dw2(mode: int, g: NeighbourTable, PQ: Tensor, H1p: int, H1: int, H2
     dev = PQ.device
     slab = torch.empty(nslab * H2 * H1, dtype=torch.float32, device=dev)
     bpart = torch.empty(nslab * H2, dtype=torch.float32, device=dev)
-    with _timed("edgeconv_dw2"):
+    with _timed("edgeconv_dw2", f"edgeconv_dw2[{H1p}x{H2}]"):
         _lib.check(L.gn_edgeconv_dw2(mode, *g.c_args(), _p(PQ), H1p, H1, H2, _p(gout), _rows(gout, "gout"), _p(mask),
                                      _p(slab), _p(bpart), _st()))
     dW2 = torch.empty((H2, H1), dtype=torch.float32, device=dev)
