@@ -410,14 +410,16 @@ __device__ __forceinline__ void fwd_phase(const unsigned char* a, const bf16x8 (
 }
 
 // =============================================================================== forward, wave-specialised
-// Same tile, operand layout and results as edge_fwd_v2_kernel, but the two halves of the work run on DIFFERENT
-// waves so that the matrix core and the vector ALU of a SIMD are busy at the same time (in the kernel above the
-// two waves of a SIMD run gather / MFMA / epilogue phases in lockstep and the pipes take turns):
-//   * waves 0-7  = consumers: stationary W2 slice, 44 MFMAs per tile from the LDS tile, relu / slot-sum / slot-mask
-//     epilogue, output stores;
-//   * waves 8-11 = producers (one per SIMD beside two consumers): gather P[i], Q[j] of the NEXT tile (4 threads per
-//     edge row, loads issued one whole tile ahead), h = relu(P + Q) -> the other LDS buffer.
-// One barrier per tile; 12 waves = 3 per SIMD (VGPR budget 168).
+// Same tile and operand layout as edge_fwd_v2_kernel (results equal up to the summation order of the slot sums).
+// In the kernel above the two waves of a SIMD run gather / MFMA / epilogue phases in lockstep and the vector and
+// matrix pipes take turns (co-execution 8 % of the cycles).  Here
+//   * waves 8-11 = producers (one per SIMD): gather P[i], Q[j] of the tile after next (4 threads per edge row, the
+//     loads are in flight for a whole tile), h = relu(P + Q) -> the other LDS buffer;
+//   * waves 0-7  = consumers: stationary (negated) W2 slice, two 21-step MFMA chains per tile (rows 0-31, 32-63)
+//     read from the LDS tile, and BETWEEN the MFMAs of a chain the relu / slot-sum / slot-mask epilogue of the
+//     previous chain's accumulators (fwd_phase): vector instructions of the same wave issue in the free slots of
+//     its MFMAs, vector work of another wave does not (measured: DESIGN.md section 5).
+// One barrier per tile; 12 waves = 3 per SIMD (VGPR budget 168: W2 slice 84, two accumulator tiles 32).
 constexpr int WS_THREADS = 768;
 // KSTEPS = H1p / 16 (row layout of P|Q and W2p), KUSE = ceil(H1 / 16) <= KSTEPS: the k-steps that hold real columns
 // (H1 = 336: 21 of 22: the last one is the packed layout's zero padding and is neither gathered nor multiplied).
