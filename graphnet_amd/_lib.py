@@ -13,6 +13,7 @@ from ctypes import c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphnet_amd.so")
 _lib = None
+ABI_VERSION = 2          # GN_ABI_VERSION of include/graphnet_amd.h these signatures mirror
 
 P = c_void_p
 I32 = c_int32
@@ -98,6 +99,9 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
+        if handle.gn_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {handle.gn_abi_version()}, this package binds version "
+                               f"{ABI_VERSION}: rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)")
         _lib = handle
     return _lib
 

@@ -41,7 +41,7 @@ gn::EdgeGraph make_graph(const int32_t* nbr, const int32_t* oc, const int32_t* o
 extern "C" {
 
 const char* gn_last_error(void) { return g_err; }
-int gn_abi_version(void) { return 1; }
+int gn_abi_version(void) { return GN_ABI_VERSION; }
 
 int gn_knn_plan(const int32_t* ptr, int32_t B, int32_t* tile_ptr, void* stream) {
     if (B < 0 || !ptr || !tile_ptr) return bad("gn_knn_plan", "need ptr[B+1] and tile_ptr[B+1]");

@@ -35,7 +35,8 @@ extern "C" {
 #define GN_MAXSEG 6
 
 const char* gn_last_error(void);
-int gn_abi_version(void);
+#define GN_ABI_VERSION 2   /* 2: gn_edgeconv_fwd takes the real hidden width H1 */
+int gn_abi_version(void);   /* == GN_ABI_VERSION of the header the library was built from */
 
 /* ---- graph construction ------------------------------------------------------------- */
 

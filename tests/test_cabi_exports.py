@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.gn_abi_version() == 1
+    assert lib.gn_abi_version() == 2
     assert lib.gn_edge_slots(8) == 8 and lib.gn_edge_slots(9) == 16 and lib.gn_edge_slots(17) == 32
     assert lib.gn_scan_tmp_ints(150000) >= 74
     import ctypes
