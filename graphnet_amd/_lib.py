@@ -88,6 +88,12 @@ def lib() -> ctypes.CDLL:
     """Load the C-ABI library (never falls back to anything else)."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and os.environ.get("GN_NO_AUTOBUILD") != "1" and \
+                os.path.exists(os.path.join(_HERE, "csrc", "Makefile")):
+            try:                                    # a checkout without build artefacts: compile once (hipcc, ~1 min)
+                build()
+            except Exception:                       # no hipcc / compile error: reported by the check below
+                pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
