@@ -4,12 +4,14 @@ Host-side mirror of the reference's L3/L4 glue on the DynEdge path — plain tor
 ``models/standard_model.py:24-119``, ``models/task/task.py:22-337``,
 ``models/task/reconstruction.py:101-112``, ``training/loss_functions.py:23-112``,
 ``training/callbacks.py:25-78``, ``models/easy_model.py:215-256`` (optimizer / training step).
-Lightning is not a dependency: :meth:`StandardModel.fit` is a small explicit loop with the same
-step semantics (forward, summed task losses, backward, optimizer step, per-step LR schedule).
+Lightning is not a dependency: :meth:`StandardModel.fit` writes out the loop ``EasySyntax.fit`` hands to the Lightning
+trainer (``easy_model.py:83-184``): step semantics, validation, early stopping, best checkpoint, resume.
 """
 from __future__ import annotations
 
 from typing import Any, Callable, Dict, List, Optional, Sequence, Type, Union
+
+import os
 
 import numpy as np
 import torch
@@ -410,29 +412,124 @@ class StandardModel(Model):
                 task.train_eval()
         return self
 
-    def fit(self, train_batches: Sequence[Any], max_epochs: int = 1, device: str = "cuda",
-            grad_sync: Optional[Callable[[], None]] = None, log_every: int = 0) -> List[float]:
-        """Minimal explicit training loop with the step semantics of ``easy_model.py:237-256``.
-        ``grad_sync`` (e.g. ``FlatGradAllReduce.__call__``) runs between backward and step."""
+    @staticmethod
+    def _batch_events(batch: Union[Any, List[Any]]) -> int:
+        """Events in a batch from ``ptr`` / ``n_pulses`` (the reference runs ``torch.unique(batch)`` every step,
+        ``model.py:28-30``: a device sync)."""
+        parts = batch if isinstance(batch, (list, tuple)) else [batch]
+        return sum(int(b.n_pulses.shape[0]) if getattr(b, "n_pulses", None) is not None and b.n_pulses.dim() > 0
+                   else int(b.ptr.shape[0]) - 1 for b in parts)
+
+    def _epoch_mean(self, total: Tensor, count: int) -> float:
+        """Batch-size weighted mean of the step losses of an epoch, summed over ranks (``sync_dist=True``)."""
+        import torch.distributed as dist
+        acc = torch.stack([total.detach().double().reshape(()), torch.tensor(float(count), dtype=torch.float64,
+                                                                             device=total.device)])
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(acc)
+        return float(acc[0] / acc[1].clamp_min(1.0))
+
+    def fit(self, train_dataloader: Sequence[Any], val_dataloader: Optional[Sequence[Any]] = None, *,
+            max_epochs: int = 10, early_stopping_patience: int = 5, ckpt_path: Optional[str] = None,
+            log_every_n_steps: int = 1, gradient_clip_val: Optional[float] = None, default_root_dir: Optional[str] = None,
+            device: str = "cuda", grad_sync: Optional[Callable[[], None]] = None) -> Dict[str, List[float]]:
+        """The training loop ``EasySyntax.fit`` hands to ``pytorch_lightning.Trainer`` (``easy_model.py:83-184``), written
+        out: per step forward + loss + backward + optional gradient all-reduce (``grad_sync``, e.g.
+        ``FlatGradAllReduce.__call__``; created automatically when ``torch.distributed`` is initialised) + optional
+        gradient-norm clipping + optimizer and per-step scheduler; per epoch the batch-size weighted ``train_loss`` and,
+        with a validation loader, ``val_loss`` (no grad, eval mode), early stopping on it (``patience`` epochs without
+        improvement) and ONE best checkpoint ``{Backbone}-epoch=..-val_loss=..-train_loss=...ckpt`` (Lightning layout)
+        whose weights are loaded back at the end (``l.177-184``).  ``ckpt_path`` resumes weights, optimizer state and the
+        epoch counter.  Ctrl-C leaves the loop gracefully.  Returns (and keeps in ``self.history``) the logged series
+        ``train_loss`` / ``val_loss`` per epoch and ``lr`` every ``log_every_n_steps`` steps."""
+        import torch.distributed as dist
         self.to(device)
-        self.train()
+        self.train(mode=True)
         optimizer, scheduler = self.configure_optimizers()
-        history: List[float] = []
-        step = 0
-        for _epoch in range(max_epochs):
-            for batch in train_batches:
-                batch = batch.to(device) if isinstance(batch, Data) else batch
-                loss = self.shared_step(batch, step)
-                optimizer.zero_grad(set_to_none=True)
-                loss.backward()
-                if grad_sync is not None:
-                    grad_sync()
-                optimizer.step()
-                if scheduler is not None:
-                    scheduler.step()
-                step += 1
-                if log_every and step % log_every == 0:
-                    history.append(float(loss.detach()))
+        start_epoch, step = 0, 0
+        if ckpt_path is not None:
+            rest = self.load_checkpoint(ckpt_path)
+            if rest.get("optimizer_states"):
+                optimizer.load_state_dict(rest["optimizer_states"][0])
+            if scheduler is not None and rest.get("lr_schedulers"):
+                scheduler.load_state_dict(rest["lr_schedulers"][0])
+            start_epoch, step = int(rest.get("epoch", -1)) + 1, int(rest.get("global_step", 0))
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if grad_sync is None and distributed:
+            from .parallel import FlatGradAllReduce
+            grad_sync = FlatGradAllReduce(self.parameters())
+        zero = grad_sync.zero_grad if hasattr(grad_sync, "zero_grad") else (lambda: optimizer.zero_grad(set_to_none=True))
+        rank0 = not distributed or dist.get_rank() == 0
+        history: Dict[str, List[float]] = {"train_loss": [], "val_loss": [], "lr": []}
+        best, best_path, waited = float("inf"), None, 0
+        ckpt_dir = os.path.join(default_root_dir or os.getcwd(), "checkpoints")
+        params = [p for p in self.parameters() if p.requires_grad]
+
+        def run_epoch(loader: Sequence[Any], training: bool) -> float:
+            nonlocal step
+            total, count = None, 0
+            for i, batch in enumerate(loader):
+                batch = batch.to(device) if isinstance(batch, Data) else [b.to(device) for b in batch]
+                if training:
+                    zero()
+                    loss = self.shared_step(batch, i)
+                    loss.backward()
+                    if grad_sync is not None:
+                        grad_sync()
+                    if gradient_clip_val is not None:
+                        torch.nn.utils.clip_grad_norm_(params, gradient_clip_val)
+                    optimizer.step()
+                    if scheduler is not None:
+                        scheduler.step()
+                    step += 1
+                    if log_every_n_steps and step % log_every_n_steps == 0:
+                        history["lr"].append(float(optimizer.param_groups[0]["lr"]))
+                else:
+                    with torch.no_grad():
+                        loss = self.shared_step(batch, i)
+                n = self._batch_events(batch)
+                total = loss.detach() * n if total is None else total + loss.detach() * n
+                count += n
+            if total is None:
+                total = torch.zeros((), device=device)
+            return self._epoch_mean(total, count)
+
+        try:
+            for epoch in range(start_epoch, max_epochs):
+                self.train(mode=True)
+                train_loss = run_epoch(train_dataloader, True)
+                history["train_loss"].append(train_loss)
+                if val_dataloader is None:
+                    continue
+                self.eval()
+                val_loss = run_epoch(val_dataloader, False)
+                self.train(mode=True)
+                history["val_loss"].append(val_loss)
+                if val_loss < best:
+                    best, waited = val_loss, 0
+                    if rank0:
+                        os.makedirs(ckpt_dir, exist_ok=True)
+                        if best_path is not None and os.path.exists(best_path):
+                            os.remove(best_path)                      # save_top_k = 1
+                        best_path = os.path.join(ckpt_dir, f"{self.backbone.__class__.__name__}-epoch={epoch}"
+                                                           f"-val_loss={val_loss:.2f}-train_loss={train_loss:.2f}.ckpt")
+                        self.save_checkpoint(best_path, optimizer, epoch=epoch, global_step=step, scheduler=scheduler)
+                else:
+                    waited += 1
+                    if waited >= early_stopping_patience:
+                        break
+        except KeyboardInterrupt:                                     # "[ctrl+c] Exiting gracefully." (l.172-174)
+            pass
+        if val_dataloader is not None:
+            if distributed:                                           # every rank reloads what rank 0 wrote
+                box = [best_path]
+                dist.broadcast_object_list(box, src=0)
+                best_path = box[0]
+                dist.barrier()
+            if best_path is not None and os.path.exists(best_path):
+                self.load_checkpoint(best_path)
+                self.to(device)
+        self.history, self.best_model_path = history, best_path
         return history
 
     def predict_as_dataframe(self, batches: Sequence[Any], prediction_columns: Optional[List[str]] = None, *,
@@ -466,12 +563,26 @@ class StandardModel(Model):
 
     # Lightning ``ModelCheckpoint`` layout (``easy_model.py:143-170``: ``.ckpt`` files hold ``state_dict`` next to the
     # trainer counters); written with tensors only, read with ``weights_only=True``
+    @staticmethod
+    def _plain(obj: Any) -> Any:
+        """numpy scalars / arrays (``PiecewiseLinearLR`` keeps ``np.interp`` results) as Python numbers / lists, so that
+        the checkpoint holds tensors and plain containers only and loads with ``weights_only=True``."""
+        if isinstance(obj, dict):
+            return {k: StandardModel._plain(v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(StandardModel._plain(v) for v in obj)
+        if isinstance(obj, np.generic):
+            return obj.item()
+        if isinstance(obj, np.ndarray):
+            return obj.tolist()
+        return obj
+
     def save_checkpoint(self, path: str, optimizer: Optional[torch.optim.Optimizer] = None, epoch: int = 0,
-                        global_step: int = 0) -> None:
+                        global_step: int = 0, scheduler: Any = None) -> None:
         ckpt: Dict[str, Any] = {"epoch": epoch, "global_step": global_step, "pytorch-lightning_version": "2.0.0",
                                 "state_dict": self.state_dict(), "loops": None, "callbacks": {},
-                                "optimizer_states": [optimizer.state_dict()] if optimizer is not None else [],
-                                "lr_schedulers": []}
+                                "optimizer_states": [self._plain(optimizer.state_dict())] if optimizer is not None else [],
+                                "lr_schedulers": [self._plain(scheduler.state_dict())] if scheduler is not None else []}
         torch.save(ckpt, path)
 
     def load_checkpoint(self, path: str, strict: bool = True) -> Dict[str, Any]:

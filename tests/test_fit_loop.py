@@ -1,0 +1,135 @@
+"""StandardModel.fit (easy_model.py:83-184 without Lightning): validation, early stopping, best checkpoint, resume,
+gradient clipping and the world-size-2 (gloo) loop.  CPU only: the backbone is a small plain-torch stand-in with the
+GNN plugin interface (the HIP backbones need the MI355X)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import graphnet_amd as g
+from graphnet_amd.synthetic import synthetic_icecube86_batch
+
+
+class _MeanBackbone(g.GNN):
+    """Per-event feature mean -> Linear: enough of a backbone for the loop logic."""
+
+    def __init__(self, nb_inputs: int = 7, nb_outputs: int = 16):
+        super().__init__(nb_inputs, nb_outputs)
+        self.lin = torch.nn.Linear(nb_inputs, nb_outputs)
+
+    def forward(self, data):
+        B = int(data.n_pulses.shape[0])
+        s = torch.zeros(B, data.x.shape[1]).index_add_(0, data.batch, data.x)
+        return torch.relu(self.lin(s / data.n_pulses.clamp_min(1).unsqueeze(1).float()))
+
+
+def _model(lr: float, **kw):
+    torch.manual_seed(0)
+    return g.StandardModel(graph_definition=g.KNNGraph(g.IceCube86()), backbone=_MeanBackbone(),
+                           tasks=[g.EnergyReconstruction(hidden_size=16, loss_function=g.LogCoshLoss(),
+                                                         transform_prediction_and_target=torch.log10)],
+                           optimizer_kwargs={"lr": lr}, **kw)
+
+
+def _loaders():
+    train = [synthetic_icecube86_batch(6, seed=s) for s in (1, 2, 3)]
+    val = [synthetic_icecube86_batch(5, seed=9), synthetic_icecube86_batch(3, seed=10)]
+    return train, val
+
+
+def test_fit_validation_early_stopping_and_best_checkpoint(tmp_path):
+    train, val = _loaders()
+    m = _model(lr=0.0)                                   # nothing improves after the first epoch
+    hist = m.fit(train, val, max_epochs=20, early_stopping_patience=3, default_root_dir=str(tmp_path), device="cpu")
+    assert len(hist["train_loss"]) == len(hist["val_loss"]) == 1 + 3          # best epoch + patience
+    assert len(hist["lr"]) == 4 * len(train) and all(v == 0.0 for v in hist["lr"])
+    # batch-size weighted epoch mean (Lightning's on_epoch reduction), not the mean of the batch losses
+    m.eval()
+    with torch.no_grad():
+        per = [(float(m.shared_step(b)), int(b.n_pulses.shape[0])) for b in val]
+    assert abs(hist["val_loss"][0] - sum(l * n for l, n in per) / sum(n for _, n in per)) < 1e-6
+    files = os.listdir(tmp_path / "checkpoints")
+    assert len(files) == 1 and files[0].startswith("_MeanBackbone-epoch=0-val_loss=") and files[0].endswith(".ckpt")
+    assert m.best_model_path == str(tmp_path / "checkpoints" / files[0])
+    ck = torch.load(m.best_model_path, weights_only=True)
+    assert {"state_dict", "optimizer_states", "lr_schedulers", "epoch", "global_step",
+            "pytorch-lightning_version"} <= set(ck)
+    assert ck["epoch"] == 0 and ck["global_step"] == len(train)
+
+
+def test_fit_trains_keeps_top1_and_reloads_best(tmp_path):
+    train, val = _loaders()
+    m = _model(lr=5e-2)
+    hist = m.fit(train, val, max_epochs=6, early_stopping_patience=6, gradient_clip_val=0.5,
+                 default_root_dir=str(tmp_path), device="cpu")
+    assert len(hist["train_loss"]) == 6 and hist["train_loss"][-1] < hist["train_loss"][0]
+    assert len(os.listdir(tmp_path / "checkpoints")) == 1                      # save_top_k = 1
+    best_epoch = int(np.argmin(hist["val_loss"]))
+    assert f"-epoch={best_epoch}-" in m.best_model_path
+    # the weights in memory are the best epoch's, not the last epoch's
+    ck = torch.load(m.best_model_path, weights_only=True)["state_dict"]
+    assert all(torch.equal(v, ck[k]) for k, v in m.state_dict().items())
+
+
+def test_fit_resumes_from_checkpoint(tmp_path):
+    train, val = _loaders()
+    sched = dict(scheduler_class=g.PiecewiseLinearLR,
+                 scheduler_kwargs={"milestones": [0, 6, 30], "factors": [1e-2, 1.0, 1e-2]})
+    a = _model(lr=1e-2, **sched)
+    a.fit(train, max_epochs=2, device="cpu")
+    opt, sch = a.configure_optimizers()
+    # a fresh two-epoch run saved by hand = what a ModelCheckpoint would have written after epoch 1
+    b = _model(lr=1e-2, **sched)
+    hist_b = b.fit(train, max_epochs=2, device="cpu")
+    assert len(hist_b["train_loss"]) == 2 and not hist_b["val_loss"]
+    opt_b, sch_b = b.configure_optimizers()
+    for _ in range(2 * len(train)):
+        opt_b.step(); sch_b.step()                        # scheduler position after two epochs
+    path = str(tmp_path / "resume.ckpt")
+    b.save_checkpoint(path, opt_b, epoch=1, global_step=2 * len(train), scheduler=sch_b)
+    c = _model(lr=1e-2, **sched)
+    hist_c = c.fit(train, max_epochs=5, ckpt_path=path, device="cpu")
+    assert len(hist_c["train_loss"]) == 3                 # epochs 2, 3, 4
+    assert abs(hist_c["lr"][0] - 1e-2 * np.interp(2 * len(train) + 1, [0, 6, 30], [1e-2, 1.0, 1e-2])) < 1e-12
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from graphnet_amd.parallel import broadcast_parameters
+    train = [synthetic_icecube86_batch(6, seed=10 * rank + s) for s in (1, 2)]     # disjoint event shards
+    val = [synthetic_icecube86_batch(4 + rank, seed=50 + rank)]
+    m = _model(lr=2e-2)
+    broadcast_parameters(m)
+    hist = m.fit(train, val, max_epochs=3, early_stopping_patience=3, default_root_dir=root, device="cpu")
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    q.put((rank, flat.numpy().copy(), hist, m.best_model_path))
+    dist.destroy_process_group()
+
+
+def test_fit_world2_gloo_ranks_agree(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]), "weights after fit must be identical on every rank"
+    assert res[0][2]["train_loss"] == res[1][2]["train_loss"] and res[0][2]["val_loss"] == res[1][2]["val_loss"]
+    assert res[0][3] == res[1][3] and len(os.listdir(tmp_path / "checkpoints")) == 1
