@@ -311,3 +311,25 @@ def test_flat_buffer_device_batch_equals_per_event_loader_path():
     yh, th = m(host, return_trace=True)
     assert torch.equal(td["graphs"][0].nbr, th["graphs"][0].nbr)        # same layer-1 graph (coordinates are exact)
     assert rel_err(yd, yh.detach()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_fit_loop_on_the_hip_backbone(tmp_path):
+    """StandardModel.fit end to end on the device path: train / validate / best checkpoint / reload."""
+    import graphnet_amd as g
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    torch.manual_seed(0)
+    m = g.StandardModel(graph_definition=g.KNNGraph(g.IceCube86()),
+                        backbone=g.DynEdge(7, global_pooling_schemes=["min", "max", "mean", "sum"]),
+                        tasks=[g.EnergyReconstruction(hidden_size=128, loss_function=g.LogCoshLoss(),
+                                                      transform_prediction_and_target=torch.log10)],
+                        optimizer_kwargs={"lr": 1e-3, "eps": 1e-3})
+    train = [synthetic_icecube86_batch(16, seed=s) for s in (1, 2, 3, 4)]
+    val = [synthetic_icecube86_batch(16, seed=9)]
+    hist = m.fit(train, val, max_epochs=4, early_stopping_patience=4, gradient_clip_val=1.0,
+                 default_root_dir=str(tmp_path), device="cuda")
+    assert len(hist["train_loss"]) == 4 and all(np.isfinite(hist["train_loss"] + hist["val_loss"]))
+    assert hist["train_loss"][-1] < hist["train_loss"][0]
+    assert m.best_model_path is not None and "DynEdge-epoch=" in m.best_model_path
+    preds = m.predict(val)
+    assert preds[0].shape == (16, 1) and bool(torch.isfinite(preds[0]).all())
