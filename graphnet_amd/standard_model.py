@@ -432,7 +432,8 @@ class StandardModel(Model):
     def fit(self, train_dataloader: Sequence[Any], val_dataloader: Optional[Sequence[Any]] = None, *,
             max_epochs: int = 10, early_stopping_patience: int = 5, ckpt_path: Optional[str] = None,
             log_every_n_steps: int = 1, gradient_clip_val: Optional[float] = None, default_root_dir: Optional[str] = None,
-            device: str = "cuda", grad_sync: Optional[Callable[[], None]] = None) -> Dict[str, List[float]]:
+            save_dir: Optional[str] = None, device: str = "cuda",
+            grad_sync: Optional[Callable[[], None]] = None) -> Dict[str, List[float]]:
         """The training loop ``EasySyntax.fit`` hands to ``pytorch_lightning.Trainer`` (``easy_model.py:83-184``), written
         out: per step forward + loss + backward + optional gradient all-reduce (``grad_sync``, e.g.
         ``FlatGradAllReduce.__call__``; created automatically when ``torch.distributed`` is initialised) + optional
@@ -440,7 +441,9 @@ class StandardModel(Model):
         with a validation loader, ``val_loss`` (no grad, eval mode), early stopping on it (``patience`` epochs without
         improvement) and ONE best checkpoint ``{Backbone}-epoch=..-val_loss=..-train_loss=...ckpt`` (Lightning layout)
         whose weights are loaded back at the end (``l.177-184``).  ``ckpt_path`` resumes weights, optimizer state and the
-        epoch counter.  Ctrl-C leaves the loop gracefully.  Returns (and keeps in ``self.history``) the logged series
+        epoch counter.  ``save_dir`` adds what ``GraphnetEarlyStopping`` (``training/callbacks.py:163-249``) writes:
+        ``config.yml`` at the start and ``best_model.pth`` (plain state dict) at every improvement.  Ctrl-C leaves the
+        loop gracefully.  Returns (and keeps in ``self.history``) the logged series
         ``train_loss`` / ``val_loss`` per epoch and ``lr`` every ``log_every_n_steps`` steps."""
         import torch.distributed as dist
         self.to(device)
@@ -464,6 +467,9 @@ class StandardModel(Model):
         best, best_path, waited = float("inf"), None, 0
         ckpt_dir = os.path.join(default_root_dir or os.getcwd(), "checkpoints")
         params = [p for p in self.parameters() if p.requires_grad]
+        if save_dir is not None and rank0:
+            os.makedirs(save_dir, exist_ok=True)
+            self.save_config(os.path.join(save_dir, "config.yml"))
 
         def run_epoch(loader: Sequence[Any], training: bool) -> float:
             nonlocal step
@@ -514,6 +520,8 @@ class StandardModel(Model):
                         best_path = os.path.join(ckpt_dir, f"{self.backbone.__class__.__name__}-epoch={epoch}"
                                                            f"-val_loss={val_loss:.2f}-train_loss={train_loss:.2f}.ckpt")
                         self.save_checkpoint(best_path, optimizer, epoch=epoch, global_step=step, scheduler=scheduler)
+                        if save_dir is not None:
+                            self.save_state_dict(os.path.join(save_dir, "best_model.pth"))
                 else:
                     waited += 1
                     if waited >= early_stopping_patience:

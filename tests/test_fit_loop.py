@@ -65,7 +65,11 @@ def test_fit_trains_keeps_top1_and_reloads_best(tmp_path):
     train, val = _loaders()
     m = _model(lr=5e-2)
     hist = m.fit(train, val, max_epochs=6, early_stopping_patience=6, gradient_clip_val=0.5,
-                 default_root_dir=str(tmp_path), device="cpu")
+                 default_root_dir=str(tmp_path), save_dir=str(tmp_path / "es"), device="cpu")
+    # GraphnetEarlyStopping's files: the model config and the best state dict (same weights as the checkpoint)
+    assert sorted(os.listdir(tmp_path / "es")) == ["best_model.pth", "config.yml"]
+    sd = torch.load(tmp_path / "es" / "best_model.pth", weights_only=True)
+    assert all(torch.equal(v, sd[k]) for k, v in m.state_dict().items())
     assert len(hist["train_loss"]) == 6 and hist["train_loss"][-1] < hist["train_loss"][0]
     assert len(os.listdir(tmp_path / "checkpoints")) == 1                      # save_top_k = 1
     best_epoch = int(np.argmin(hist["val_loss"]))
