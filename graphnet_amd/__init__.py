@@ -5,7 +5,7 @@ Host-side mirrors of the reference interface (``Data``/``Batch``, ``Detector``, 
 hand-written gfx950 HIP kernels (``include/graphnet_amd.h``).  Importing the package never
 needs a GPU; calling a device op without the built library raises ``RuntimeError``.
 """
-from .data import Batch, Data, collate_fn  # noqa: F401
+from .data import Batch, Data, collate_fn, collator_sequence_buckleting  # noqa: F401
 from .detector import Detector, IceCube86, IceCubeDeepCore, IceCubeUpgrade, ORCA150SuperDense, Prometheus  # noqa: F401
 from .model import Model, ModelConfig  # noqa: F401
 from .graphs import GraphDefinition, KNNEdges, KNNGraph, NodesAsPulses  # noqa: F401

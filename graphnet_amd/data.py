@@ -78,8 +78,8 @@ class Batch(Data):
     @classmethod
     def from_data_list(cls, graphs: List[Data]) -> "Batch":
         """Restates PyG's concatenation rules for the attributes on this path:
-        node-level tensors (first dim == num_nodes) are concatenated, ``edge_index`` is
-        offset by the cumulative node count, 0-d tensors/scalars are stacked to ``[B]``."""
+        tensors with at least one dimension are concatenated along dim 0, ``edge_index`` along dim 1 after
+        being offset by the cumulative node count, 0-d tensors / Python scalars are stacked to ``[B]``."""
         out = cls()
         sizes = [g.num_nodes for g in graphs]
         ptr = torch.zeros(len(graphs) + 1, dtype=torch.int64)
@@ -91,10 +91,10 @@ class Batch(Data):
             v0 = vals[0]
             if k == "edge_index":
                 out[k] = torch.cat([v + int(ptr[i]) for i, v in enumerate(vals)], dim=1)
-            elif isinstance(v0, Tensor) and v0.dim() >= 1 and v0.shape[0] == sizes[0] and k != "n_pulses":
-                out[k] = torch.cat(vals, dim=0)
+            elif isinstance(v0, Tensor) and v0.dim() >= 1:
+                out[k] = torch.cat(vals, dim=0)           # node-level rows and per-event rows alike (e.g. a [1, 1] loss weight -> [B, 1])
             elif isinstance(v0, Tensor):
-                out[k] = torch.stack([v.reshape(()) if v.numel() == 1 else v for v in vals], dim=0)
+                out[k] = torch.stack(vals, dim=0)         # 0-d: n_pulses, scalar labels -> [B]
             elif isinstance(v0, (int, float)):
                 out[k] = torch.tensor(vals)
             else:
@@ -109,3 +109,22 @@ def collate_fn(graphs: List[Data]) -> Batch:
     """``data/dataloader.py:12-18``: drop events with <= 1 pulse, then batch."""
     graphs = [g for g in graphs if int(g.n_pulses) > 1]
     return Batch.from_data_list(graphs)
+
+
+class collator_sequence_buckleting:
+    """``training/utils.py:31-67`` (the reference's spelling): events sorted by pulse count and cut at the given
+    fractions into several ``Batch`` objects, so that a dense-padded attention never pads short events to the
+    longest one.  ``StandardModel.forward`` takes the list as it is (``standard_model.py:96-108``)."""
+
+    def __init__(self, batch_splits: List[float] = [0.8]):
+        self.batch_splits = list(batch_splits)
+
+    def __call__(self, graphs: List[Data]) -> List[Batch]:
+        graphs = sorted((g for g in graphs if int(g.n_pulses) > 1), key=lambda g: int(g.n_pulses))
+        cuts = [0.0] + self.batch_splits + [1.0]
+        out = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            part = graphs[int(lo * len(graphs)): int(hi * len(graphs))]
+            if part:
+                out.append(Batch.from_data_list(part))
+        return out

@@ -493,3 +493,29 @@ def test_task_transform_pair_is_validated():
     train_out = t(x)
     t.inference()
     assert torch.allclose(t(x), torch.pow(10, train_out))
+
+
+def test_batch_concatenation_rules_and_sequence_bucketing():
+    """Batch.from_data_list as PyG: >= 1-d tensors concatenated along dim 0 (a [1, 1] loss weight becomes [B, 1], which
+    is what LossFunction multiplies with [B, 1] elements), 0-d stacked; collator_sequence_buckleting (training/utils.py:31-67)."""
+    rng = np.random.default_rng(0)
+    graphs = []
+    for i, n in enumerate([5, 40, 1, 12, 90, 7, 33, 60]):
+        d = g.Data(x=torch.randn(n, 4))
+        d.n_pulses = torch.tensor(n, dtype=torch.int32)
+        d["energy"] = torch.tensor(float(i + 1))
+        d["w"] = torch.tensor(0.5 * (i + 1)).reshape(-1, 1)
+        d["direction"] = torch.tensor([0.0, 0.0, 1.0]).reshape(1, 3)
+        graphs.append(d)
+    b = g.collate_fn(graphs)
+    assert b.num_graphs == 7 and b.x.shape == (247, 4)                        # the 1-pulse event is dropped
+    assert b["energy"].shape == (7,) and b["w"].shape == (7, 1) and b["direction"].shape == (7, 3)
+    assert b.n_pulses.tolist() == [5, 40, 12, 90, 7, 33, 60] and b.ptr[-1] == 247
+    # weighted loss: [B, 1] elements x [B, 1] weights (a [B] weight vector would broadcast to [B, B])
+    loss = g.LogCoshLoss()
+    pred, tgt = torch.randn(7, 1), torch.randn(7, 1)
+    el = loss(pred, tgt, return_elements=True)
+    assert torch.allclose(loss(pred, tgt, weights=b["w"]), (el * b["w"]).mean())
+    parts = g.collator_sequence_buckleting([0.5, 0.8])(graphs)
+    assert [p.n_pulses.tolist() for p in parts] == [[5, 7, 12], [33, 40], [60, 90]]
+    assert sum(p.num_graphs for p in parts) == 7
