@@ -9,7 +9,7 @@ from graphnet_amd import ops
 from graphnet_amd.synthetic import synthetic_icecube86_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
-steps = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 5
+steps = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 20
 p_drop = float(sys.argv[sys.argv.index("--dropout") + 1]) if "--dropout" in sys.argv else 0.1   # torch / reference default
 torch.manual_seed(0)
 b = synthetic_icecube86_batch(B, seed=5, count_range=(50, 3000)).to("cuda")
@@ -28,13 +28,15 @@ def step():
     loss.backward()
     opt.step()
     return loss
-for _ in range(2): l = step()
+for _ in range(30): l = step()          # clock ramp-up + allocator growth
 torch.cuda.synchronize()
-ops.enable_timers(True)
 t0 = time.perf_counter()
 for _ in range(steps): l = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+ops.enable_timers(True)                 # per-op HIP events (adds host work: not part of the timed steps above)
+for _ in range(steps): step()
+torch.cuda.synchronize()
 n = b.n_pulses.double()
 print(f"config4 dropout={p_drop} B={B} N={b.x.shape[0]} (pulses/event {int(n.min())}..{int(n.max())}, sum n^2 = {float((n*n).sum()):.3g}) {dtype}: "
       f"{1e3*dt:.1f} ms/step  {B/dt:.1f} events/s  {b.x.shape[0]/dt/1e6:.2f} Mpulses/s  loss {float(l):.4f}")
