@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=10, help="eager steps with per-op HIP events (roofline)")
     ap.add_argument("--extra-events", type=int, default=1024,
                     help="also report events/s at this many events per GPU (SURVEY 8d: B in {256,1024,4096}); 0 = skip")
+    ap.add_argument("--overlap", action="store_true",
+                    help="graph building on a second HIP stream (opt-in: dispatcher-dependent, see DESIGN.md)")
     ap.add_argument("--cpu-events", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
@@ -149,6 +151,8 @@ def main():
     _lib.lib()                                           # fail loudly if the HIP library is missing
 
     model = build_model(args.dtype).to(dev)
+    if args.overlap:
+        model.backbone.set_backend(overlap=True)
     broadcast_parameters(model)
     sync = FlatGradAllReduce(model.parameters())
     # Adam(lr 1e-3, eps 1e-3) as in the reference example (easy_model.py:215-235).  Eager launches use torch's
