@@ -163,3 +163,31 @@ def test_c_oracle_under_address_and_ub_sanitizers():
     res = subprocess.run(["make", "-C", here, "selftest"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert res.returncode == 0, res.stdout[-2000:]
     assert "knn_selftest: ok" in res.stdout
+
+
+def test_knn_oracle_agrees_with_independent_exact_knn(oracle):
+    """The k-NN restatement against two independent exact nearest-neighbour implementations that ARE installed here
+    (scipy's cKDTree - a KD-tree like the nanoflann tree behind torch_cluster's CPU knn - and scikit-learn's brute
+    force), per event, on tie-free points: same neighbours in the same (ascending distance) order, no self loops,
+    edges grouped by target.  This pins the geometry of the restatement; the tie rules (duplicated positions) stay
+    the restatement's own definition."""
+    from scipy.spatial import cKDTree
+    from sklearn.neighbors import NearestNeighbors
+    rng = np.random.default_rng(11)
+    sizes = [3, 9, 40, 150, 700]                      # incl. an event with fewer than k+1 points
+    x = torch.from_numpy(rng.normal(size=(sum(sizes), 3)).astype(np.float32))
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    for k in (8, 16):
+        ei = oracle.knn_graph(x, k, batch, [0, 1, 2]).numpy()
+        assert (ei[0] != ei[1]).all() and (np.diff(ei[1]) >= 0).all()
+        lo = 0
+        for n in sizes:
+            pts = x[lo:lo + n].numpy().astype(np.float64)
+            kk = min(k, n - 1)
+            d_tree, j_tree = cKDTree(pts).query(pts, k=kk + 1)
+            j_brute = NearestNeighbors(n_neighbors=kk + 1, algorithm="brute").fit(pts).kneighbors(pts, return_distance=False)
+            for i in range(n):
+                mine = ei[0][ei[1] == lo + i] - lo
+                assert mine.tolist() == j_tree[i, 1:].tolist() == j_brute[i, 1:].tolist(), (k, n, i)
+                assert j_tree[i, 0] == i and np.all(np.diff(d_tree[i]) > 0)     # tie-free by construction
+            lo += n
