@@ -191,3 +191,45 @@ def test_knn_oracle_agrees_with_independent_exact_knn(oracle):
                 assert mine.tolist() == j_tree[i, 1:].tolist() == j_brute[i, 1:].tolist(), (k, n, i)
                 assert j_tree[i, 0] == i and np.all(np.diff(d_tree[i]) > 0)     # tie-free by construction
             lo += n
+
+
+def test_segment_ops_homophily_and_edgeconv_against_loop_restatements(oracle):
+    """The scatter / homophily / EdgeConv restatements against plain per-event, per-edge Python loops in float64
+    (the published semantics: empty segments -> 0, mean divides by max(count, 1), 'edge' homophily is the mean of
+    [y[src] == y[dst]] per graph of the target node, EdgeConv message nn([x_i, x_j - x_i]) summed / averaged / maxed
+    over the edges whose target is i)."""
+    rng = np.random.default_rng(5)
+    sizes = [4, 0, 7, 1, 12]                                     # incl. an empty segment
+    n, B = sum(sizes), len(sizes)
+    batch = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes))
+    src = torch.from_numpy(rng.normal(size=(n, 5)).astype(np.float32))
+    ref = {k: np.zeros((B, 5)) for k in ("sum", "mean", "min", "max")}
+    for b in range(B):
+        rows = src[batch == b].double().numpy()
+        if len(rows):
+            ref["sum"][b], ref["mean"][b] = rows.sum(0), rows.mean(0)
+            ref["min"][b], ref["max"][b] = rows.min(0), rows.max(0)
+    for name, fn in (("sum", oracle.scatter_sum), ("mean", oracle.scatter_mean), ("min", oracle.scatter_min), ("max", oracle.scatter_max)):
+        assert np.allclose(fn(src, batch, B).numpy(), ref[name], rtol=1e-6, atol=1e-6), name
+    # homophily on a graph with duplicated coordinate values
+    y = torch.from_numpy(rng.integers(0, 3, size=n).astype(np.float32))
+    ei = oracle.knn_graph(src[:, :3], 3, batch, [0, 1, 2])
+    want = np.zeros(B)
+    for b in range(B):
+        sel = (batch[ei[1]] == b).numpy()
+        if sel.any():
+            want[b] = np.mean((y[ei[0]][sel] == y[ei[1]][sel]).numpy())
+    assert np.allclose(oracle.homophily(ei, y, batch, B).reshape(-1).numpy(), want, atol=1e-7)
+    # EdgeConv, all three aggregations
+    torch.manual_seed(2)
+    mlp = torch.nn.Sequential(torch.nn.Linear(10, 6), torch.nn.ReLU(), torch.nn.Linear(6, 4), torch.nn.ReLU()).double()
+    xd = src.double()
+    for aggr in ("add", "mean", "max"):
+        want = torch.zeros(n, 4, dtype=torch.float64)
+        for i in range(n):
+            js = ei[0][ei[1] == i]
+            if len(js):
+                msg = torch.stack([mlp(torch.cat([xd[i], xd[j] - xd[i]])) for j in js])
+                want[i] = {"add": msg.sum(0), "mean": msg.mean(0), "max": msg.max(0).values}[aggr]
+        got = oracle.edge_conv(xd, ei, mlp, aggr)
+        assert torch.allclose(got, want.detach(), rtol=1e-10, atol=1e-12), aggr
