@@ -1,9 +1,17 @@
 #!/usr/bin/env python3
 """bench.py — events/s for DynEdge fwd+bwd(+Adam, +gradient all-reduce) on synthetic IceCube-86
-pulse graphs (BASELINE.json metric; workload = configs[1]), one process per GPU.
+pulse graphs (BASELINE.json metric; workload = configs[1] at N = 1, configs[2] at N > 1),
+one process per GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                  # starts the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Launching (the reference gets this from Lightning: ``Trainer(strategy="ddp", devices=gpus)``,
+``models/easy_model.py:83-112``): when ``--gpus N > 1`` and ``WORLD_SIZE`` is not set, this process is only a
+launcher.  Before ANY ``torch.cuda`` / HIP call (and never through ``exec``) it starts N children of itself with
+``RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT``, forwards rank 0's single JSON line
+and exits non-zero if any child fails.  Under ``torch.distributed.run`` the environment is already there and
+``--gpus`` must equal ``WORLD_SIZE`` (otherwise the run would silently measure something else: exit 2).
 
 A step = one pass of the hot path over one batch of B events already resident in HBM:
 layer-1 k-NN build, global variables, 4x(P|Q GEMM, fused EdgeConv, re-kNN), post MLP, pooling,
@@ -13,6 +21,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,8 +34,140 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+RAMP_UP_STEPS = 80             # untimed steps before the W warm-up steps (clock / allocator ramp, see below)
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
 
+# ------------------------------------------------------------------------------------------- launcher
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv, dry: bool) -> int:
+    """Parent of an N-rank run: one child per rank, rank 0's stdout forwarded, non-zero if any rank fails.
+    Nothing here touches the GPU (``torch.cuda.device_count()`` only counts devices on this image)."""
+    rehearse = os.environ.get("GN_BENCH_REHEARSE") == "1"
+    if not dry and not rehearse:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench] --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    # rank 0 prints one short line: reading it after exit cannot fill the pipe
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            rc = rc or code
+        if rc != 0:                      # one rank died: the others would wait in a collective for ever
+            for r in pending:
+                procs[r].terminate()
+            for r in pending:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        time.sleep(0.05)
+    out0 = (procs[0].stdout.read() or b"").decode(errors="replace")
+    for line in out0.splitlines():       # the JSON line to stdout; library chatter (gloo prints its peers) to stderr
+        print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    if rc != 0:
+        print(f"[bench] a rank exited with code {rc}", file=sys.stderr)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------- config-3 facts
+def weights_checksum(module: torch.nn.Module) -> torch.Tensor:
+    """Two int64 words over the BITS of every parameter (order-sensitive): equal words <=> bitwise equal weights."""
+    flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in module.parameters()])
+    bits = flat.view(torch.int32).to(torch.int64)
+    idx = torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 65521 + 1
+    return torch.stack([bits.sum(), (bits * idx).sum()])
+
+
+def weights_identical_across_ranks(module: torch.nn.Module) -> bool:
+    cs = weights_checksum(module)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return True
+    box = [torch.empty_like(cs) for _ in range(dist.get_world_size())]
+    dist.all_gather(box, cs)
+    return all(torch.equal(b, box[0]) for b in box)
+
+
+def allreduce_us(sync, reps: int = 20) -> float:
+    """Latency of the step's ONE exchange: the flat-gradient all-reduce alone, back to back, in microseconds."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0.0
+    cuda = sync.flat.is_cuda
+    saved = sync.flat.clone()
+    for _ in range(3):
+        sync.all_reduce()
+    if cuda:
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sync.all_reduce()
+    if cuda:
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sync.flat.copy_(saved)
+    t = torch.tensor([dt], dtype=torch.float64, device=sync.flat.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return 1e6 * float(t.item()) / reps
+
+
+def run_dry(args, rank: int, world: int) -> None:
+    """``--dry-run``: the launcher, rendezvous, flat all-reduce and the config-3 report fields on CPU over gloo with a
+    stand-in network - no kernel runs and ``value`` is null.  For the CPU test of the N-rank control flow only."""
+    from graphnet_amd.parallel import FlatGradAllReduce, broadcast_parameters
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                        # different initial weights per rank ...
+    net = torch.nn.Sequential(torch.nn.Linear(7, 32), torch.nn.ReLU(), torch.nn.Linear(32, 1))
+    broadcast_parameters(net)                            # ... made identical, as in the real run
+    sync = FlatGradAllReduce(net.parameters())
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-3)
+    gen = torch.Generator().manual_seed(20241016 + rank)
+    x = torch.randn(64, 7, generator=gen)
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        sync.zero_grad()
+        net(x).pow(2).mean().backward()
+        sync()
+        opt.step()
+    dt = time.perf_counter() - t0
+    same = weights_identical_across_ranks(net)
+    us = allreduce_us(sync, reps=5)
+    if rank == 0:
+        print(json.dumps({"metric": "events/sec DynEdge fwd+bwd, IceCube-86 k=8", "value": None, "unit": "events/s",
+                          "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * dt / max(args.steps + args.warmup, 1), "dry_run": True,
+                          "backend": dist.get_backend() if world > 1 else None,
+                          "allreduce_us_per_step": us, "weights_identical_across_ranks": same}))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------- the workload
 def build_model(dtype: str):
     import graphnet_amd as g
     torch.manual_seed(20241016)                       # identical initial weights on every rank
@@ -76,15 +218,64 @@ def algorithmic_flops(n_nodes: int, n_edges: int, n_events: int, F0: int = 19, n
                   + n_nodes * ((F0 + 1024) * 336 + 336 * 256) + n_events * (n_pool * 256 * 128 + 128))
 
 
-def cpu_baseline(events: int, steps: int):
-    """The oracle (plain-torch restatement of the PyG formulation) timed on the host cores."""
+def executed_flops(n_nodes: int, n_edges: int, n_events: int, F0: int = 19, n_pool: int = 4) -> float:
+    """GEMM FLOPs the HIP path actually EXECUTES per step (fwd + bwd), MAC = 2 FLOP.  The first edge-MLP layer is
+    one per-node GEMM (P | Q), so its cost scales with N, not E: forward = P|Q GEMM + edge
+    GEMM per conv layer + post MLP + read-out; backward = dW2 and dh per edge, the P|Q weight gradient, the two
+    input-gradient contractions of layers 2-4, post-MLP weight and input gradients (raw-feature columns excluded)."""
+    conv = [(F0, 128, 256), (256, 336, 256), (256, 336, 256), (256, 336, 256)]
+    N, E = float(n_nodes), float(n_edges)
+    fwd = sum(2 * N * f * 2 * h1 + 2 * E * h1 * h2 for f, h1, h2 in conv)
+    post = 2 * N * ((F0 + 1024) * 336 + 336 * 256)
+    head = 2.0 * n_events * (n_pool * 256 * 128 + 128)
+    bwd = sum(2 * 2 * E * h1 * h2 + 2 * N * f * 2 * h1 for f, h1, h2 in conv)           # dW2, dh, dW(P|Q)
+    bwd += sum(2 * N * 2 * h1 * f for f, h1, _ in conv[1:])                             # d_in of layers 2-4
+    bwd += 2 * post - 2 * N * F0 * 336 + 2 * head                                       # post MLP dW + dX, read-out
+    return fwd + post + head + bwd
+
+
+def _log(msg: str) -> None:
+    """Progress on stderr: a GPU box kills a command that writes nothing for minutes."""
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cpu() -> dict:
+    """Cores this job may use (affinity mask, capped by the cgroup CPU quota when there is one), cores of the
+    machine, CPU model string."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    quota = None
+    try:                                                  # cgroup v2: "<quota> <period>" or "max <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        pass
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cores_available": avail, "cgroup_cpu_quota": quota, "cores_machine": os.cpu_count() or avail,
+            "cpu_model": model}
+
+
+def cpu_baseline(events: int, steps: int, warmup: int, parity_model=None, budget_s: float = 45.0):
+    """The oracle (plain-torch restatement of the PyG formulation) timed on ALL host cores this job may use
+    (3 warm-up + >= 10 timed steps; the timed loop also stops after ``budget_s`` seconds so that a slow
+    or oversubscribed host cannot stall the run - the step count actually timed is reported), and - the oracle acting
+    as the checker - the parity numbers of the HIP path on a small batch in the same run."""
     from graphnet_amd.synthetic import synthetic_icecube86_batch
     from oracle import dynedge_oracle as orc
-    try:
-        cores = len(os.sched_getaffinity(0))          # the cores this job may actually use
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("GN_CPU_BASELINE_THREADS", "32"))))
+    info = host_cpu()
+    usable = min(info["cores_available"], info["cgroup_cpu_quota"] or info["cores_available"])
+    cores = max(1, int(os.environ.get("GN_CPU_BASELINE_THREADS", usable)))
     torch.set_num_threads(cores)
     torch.manual_seed(20241016)
     m = orc.StandardModelOracle(7, global_pooling_schemes=["min", "max", "mean", "sum"], literal_distribute=True)
@@ -98,14 +289,96 @@ def cpu_baseline(events: int, steps: int):
         loss.backward()
         opt.step()
 
-    step()
+    _log(f"cpu baseline: {events} events/step on {cores} threads ({info['cpu_model']})")
+    tw = time.perf_counter()
+    done_w = 0
+    for _ in range(warmup):
+        step()
+        done_w += 1
+        if time.perf_counter() - tw > budget_s / 3:
+            break
     t0 = time.perf_counter()
+    done = 0
     for _ in range(steps):
         step()
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
     dt = time.perf_counter() - t0
-    return {"value": events * steps / dt, "unit": "events/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} fwd+bwd+Adam steps of {events} synthetic IceCube-86 events (fp32, torch CPU, "
-                      f"{cores} threads; PyG not installed: in-repo restatement of the PyG formulation)"}
+    _log(f"cpu baseline: {done} timed steps in {dt:.1f} s")
+    out = {"value": events * done / dt, "unit": "events/s", "cores": cores, "kind": "port",
+           "cores_available": info["cores_available"], "cgroup_cpu_quota": info["cgroup_cpu_quota"],
+           "cores_machine": info["cores_machine"], "cpu_model": info["cpu_model"],
+           "warmup_steps": done_w, "timed_steps": done,
+           "sample": f"{done} fwd+bwd+Adam steps (after {done_w} warm-up) of {events} synthetic IceCube-86 events "
+                     f"(fp32, torch CPU, {cores} threads = every core this job may use; PyG is not installed: "
+                     f"in-repo restatement of the PyG formulation)"}
+    if parity_model is not None:
+        _log("parity of the HIP path against the oracle (small batch, fp32 and bf16 mode)")
+        out["parity"] = parity_vs_oracle(parity_model, orc)
+    return out
+
+
+def parity_vs_oracle(model, orc, events: int = 16) -> dict:
+    """SURVEY.md 8d "parity gate in the same run": a small batch through the HIP path (fp32 mode, then bf16 mode)
+    against the oracle on the HIP path's own graphs (teacher forcing), layer-1 k-NN table bit for bit."""
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    dev = next(model.parameters()).device
+    b = synthetic_icecube86_batch(events, seed=777)
+    ref = orc.StandardModelOracle(7, global_pooling_schemes=["min", "max", "mean", "sum"])
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    saved_mode = model.backbone._compute_mode
+    res = {"events": events, "tolerance": {"fp32_rel": 1e-4, "bf16_rel": 2e-2}}
+    try:
+        for name in ("fp32", "bf16"):
+            model.backbone.set_backend(dtype=name)
+            b.to(dev)
+            with torch.no_grad():
+                lat, trace = model.backbone(b, return_trace=True)
+                pred = model._tasks[0](lat)
+            torch.cuda.synchronize()
+            b.to("cpu")
+            forced = [t.edge_index().cpu() for t in trace["graphs"]]
+            with torch.no_grad():
+                lat_o = ref.backbone(b.x, forced[0], b.batch, b.n_pulses, forced_edges=forced)
+                pred_o = orc.energy_reconstruction(lat_o, ref._affine)
+            if name == "fp32":
+                res["knn_layer1_bit_exact"] = bool(torch.equal(forced[0], orc.knn_graph(b.x, 8, b.batch, [0, 1, 2])))
+            res[f"{name}_latent_max_rel"] = float((lat.float().cpu() - lat_o).abs().max() / lat_o.abs().max())
+            res[f"{name}_pred_max_rel"] = float(((pred.float().cpu() - pred_o).abs() / pred_o.abs().clamp_min(1e-6)).max())
+    finally:
+        model.backbone._compute_mode = saved_mode
+    res["pass"] = bool(res.get("knn_layer1_bit_exact") and res["fp32_latent_max_rel"] < 1e-4
+                       and res["bf16_latent_max_rel"] < 2e-2)
+    return res
+
+
+def timed_side_run(model, sync, opt, events, seed, dev, world, fence, ramp, steps) -> dict:
+    """``steps`` timed training steps on another batch size / mode, after ``ramp`` untimed ones (same model)."""
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    big = synthetic_icecube86_batch(events, seed=seed).to(dev)
+
+    def one():
+        sync.zero_grad()
+        loss_b = model.shared_step(big)
+        loss_b.backward()
+        sync()
+        opt.step()
+    for i in range(ramp):
+        one()
+        if i % 10 == 9:
+            torch.cuda.synchronize()
+    fence()
+    tb = time.perf_counter()
+    for _ in range(steps):
+        one()
+    fence()
+    t = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {"events_per_gpu": events, "pulses_per_gpu": int(big.x.shape[0]), "steps": steps,
+            "value": events * world * steps / float(t.item()), "unit": "events/s",
+            "ms_per_step": 1e3 * float(t.item()) / steps}
 
 
 def main():
@@ -118,24 +391,45 @@ def main():
                          "the headline is B=4096, B=1024 is reported in other_batch_size)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph (experimental) instead of eager launches")
+    ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph instead of eager launches")
     ap.add_argument("--profile-steps", type=int, default=10, help="eager steps with per-op HIP events (roofline)")
     ap.add_argument("--extra-events", type=int, default=1024,
                     help="also report events/s at this many events per GPU (SURVEY 8d: B in {256,1024,4096}); 0 = skip")
+    ap.add_argument("--fp32-events", type=int, default=1024,
+                    help="also report the fp32 parity mode at this many events per GPU (0 = skip)")
     ap.add_argument("--overlap", action="store_true",
                     help="graph building on a second HIP stream (opt-in: dispatcher-dependent, see DESIGN.md)")
-    ap.add_argument("--cpu-events", type=int, default=64)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-events", type=int, default=48)
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-warmup", type=int, default=3)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / all-reduce control flow only, on CPU over gloo (no kernels, value null)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.dry_run))      # nothing above touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure a different job", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("GN_BENCH_TEST_FAIL_RANK") == str(rank):      # test hook: this rank dies before the rendezvous
+            sys.exit(3)
+        run_dry(args, rank, world)
+        return
     # Rehearsal knobs (one-GPU box only, never set by the driver): GN_BENCH_REHEARSE=1 puts every rank on
     # cuda:0 and exchanges gradients over gloo, to exercise the multi-rank control flow without a second GPU.
     rehearse = os.environ.get("GN_BENCH_REHEARSE") == "1"
     if rehearse:
         local = 0
+    elif torch.cuda.device_count() < world:
+        print(f"[bench] world size {world} but {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)                         # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local)
     if world > 1:
@@ -156,7 +450,7 @@ def main():
     broadcast_parameters(model)
     sync = FlatGradAllReduce(model.parameters())
     # Adam(lr 1e-3, eps 1e-3) as in the reference example (easy_model.py:215-235).  Eager launches use torch's
-    # fused multi-tensor implementation (one launch instead of ~10 per step); the experimental hipGraph path
+    # fused multi-tensor implementation (one launch instead of ~10 per step); the hipGraph path
     # needs the capturable variant.
     if args.graph:
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-3, capturable=True)
@@ -179,14 +473,11 @@ def main():
     launch = "eager"
     step = eager_step
     if args.graph:
-        try:
-            from graphnet_amd.graphed import GraphedTrainStep
-            graphed = GraphedTrainStep(model, opt, sync)
-            graphed(batch)                                    # capture (+ its own eager warm-up)
-            step = lambda: graphed(batch)
-            launch = "hipgraph"
-        except Exception as exc:                              # pragma: no cover - reported, never silent
-            print(f"[bench] hipGraph capture failed, running eager: {exc!r}", file=sys.stderr)
+        from graphnet_amd.graphed import GraphedTrainStep
+        graphed = GraphedTrainStep(model, opt, sync)
+        graphed(batch)                                    # capture (+ its own eager warm-up); raises if it cannot
+        step = lambda: graphed(batch)
+        launch = "hipgraph"
 
     def fence():
         torch.cuda.synchronize()
@@ -198,7 +489,8 @@ def main():
     # throughput (GPU clock / power-state ramp and allocator growth: 10.0 ms/step with 5 warm-up steps vs
     # 7.5 ms/step with 40), so a short warm-up would time the ramp instead of the steady state.
     # A FIXED number of steps: every step contains the gradient all-reduce, so all ranks must run the same count.
-    for i in range(80):
+    _log(f"rank {rank}/{world}: {args.events} events = {n_nodes} pulses per GPU; ramp-up + warm-up")
+    for i in range(RAMP_UP_STEPS):
         step()
         if i % 10 == 9:
             torch.cuda.synchronize()
@@ -210,6 +502,11 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    if rank == 0:
+        _log(f"timed region: {1e3 * dt / args.steps:.2f} ms/step; per-op timers, other batch sizes and modes next")
+    # config-3 facts: replicas bitwise identical after the timed steps, cost of the exchange
+    same_weights = weights_identical_across_ranks(model)
+    ar_alone_us = allreduce_us(sync)
     # per-kernel durations: HIP events on the launch stream around every C-ABI op.  A graph replay has
     # no per-kernel events, so the same kernels are timed in a few eager steps right after the timed
     # region (same process, same buffers); rocprofv3 --kernel-trace of this command must agree.
@@ -219,42 +516,36 @@ def main():
     host_issue_ms = 1e3 * (time.perf_counter() - th)
     fence()
     ops.enable_timers(True)
-    for _ in range(max(1, args.profile_steps)):
-        eager_step()
+    ar_events = []
+    prof_steps = max(1, args.profile_steps)
+    for _ in range(prof_steps):
+        sync.zero_grad()
+        loss_p = model.shared_step(batch)
+        loss_p.backward()
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        sync()                                                # flat copy-back + the ONE all-reduce of the step
+        ev[1].record()
+        ar_events.append(ev)
+        opt.step()
     fence()
     timers = ops.timer_summary()
     detail = ops.timer_summary(detail=True)
     ops.enable_timers(False)
-    prof_steps = max(1, args.profile_steps)
+    ar_in_step_us = 1e3 * sum(a.elapsed_time(b) for a, b in ar_events) / prof_steps
     # second batch size (same model, same step), reported beside the headline value
     extra = None
     if args.extra_events and args.extra_events != args.events:
-        big = synthetic_icecube86_batch(args.extra_events, seed=20241016 + 1000 + rank).to(dev)
-        saved_batch = batch
-
-        def big_step():
-            sync.zero_grad()
-            loss_b = model.shared_step(big)
-            loss_b.backward()
-            sync()
-            opt.step()
-        for i in range(30):
-            big_step()
-            if i % 10 == 9:
-                torch.cuda.synchronize()
-        fence()
-        tb = time.perf_counter()
-        for _ in range(20):
-            big_step()
-        fence()
-        tbig = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tbig, op=dist.ReduceOp.MAX)
-        extra = {"events_per_gpu": args.extra_events, "pulses_per_gpu": int(big.x.shape[0]), "steps": 20,
-                 "value": args.extra_events * world * 20 / float(tbig.item()), "unit": "events/s",
-                 "ms_per_step": 1e3 * float(tbig.item()) / 20}
-        del big
-        batch = saved_batch
+        extra = timed_side_run(model, sync, opt, args.extra_events, 20241016 + 1000 + rank, dev, world, fence, 30, 20)
+    # fp32 parity mode (exact-f32 MFMA, fp32 storage) from the same process
+    fp32 = None
+    if args.fp32_events and args.dtype == "bf16":
+        if rank == 0:
+            _log(f"fp32 parity mode at {args.fp32_events} events per GPU")
+        model.backbone.set_backend(dtype="fp32")
+        fp32 = timed_side_run(model, sync, opt, args.fp32_events, 20241016 + 2000 + rank, dev, world, fence, 5, 8)
+        fp32["dtype"] = "f32 (v_mfma_f32_32x32x2_f32, fp32 storage)"
+        model.backbone.set_backend(dtype="bf16")
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -264,10 +555,10 @@ def main():
         total_events = args.events * world * args.steps
         # edges of the layer-1 graph (degree k or k+1) ~ edges of every layer
         with torch.no_grad():
-            from graphnet_amd import ops as _o
-            t = _o.knn_graph(batch.x, [0, 1, 2], batch.batch.to(torch.int32), batch.ptr.to(torch.int32), 8)
+            t = ops.knn_graph(batch.x, [0, 1, 2], batch.batch.to(torch.int32), batch.ptr.to(torch.int32), 8)
             n_edges = int((t.nbr >= 0).sum().item()) + int(t.ovf_cnt.item())
         flops_fwd = algorithmic_flops(n_nodes, n_edges, args.events)
+        flops_exec = executed_flops(n_nodes, n_edges, args.events)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         # dominant op group (by HIP-event time on the launch stream) priced with ITS OWN algorithmic work:
         # MFMA groups in FLOPs (2*rows*K*N of the contraction it performs), HBM groups in bytes.
@@ -313,40 +604,59 @@ def main():
         else:
             bound, unit, peak = "hbm", "GB/s", 8000.0
             achieved = hbm_bytes.get(name, 0.0) / lps / (per_launch_ms * 1e-3) / 1e9
-        # measured HBM traffic per launch of that group (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-        # passes, FETCH_SIZE doubled as the gfx950 guide prescribes), recorded in profiles/r01_traffic.json
-        traffic = None
+        # HBM traffic per launch of that group: NOT measured in this run (PMC counters need rocprofv3 passes of
+        # their own) - read from the committed summary of the `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes
+        # over this same command (FETCH_SIZE doubled as the gfx950 guide prescribes)
+        traffic, traffic_source = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
             if tj.get(name, {}).get("events_per_gpu", 1024) == args.events:      # measured on this workload only
                 traffic = tj.get(name, {}).get("bytes_per_launch")
+                traffic_source = f"from_file: {TRAFFIC_FILE}@{tj.get('_commit', 'unknown')}"
         except Exception:
             pass
         out = {
             "metric": "events/sec DynEdge fwd+bwd, IceCube-86 k=8",
-            "value": total_events / dt, "unit": "events/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "value": total_events / dt, "unit": "events/s", "n_gpus": dist.get_world_size() if world > 1 else 1,
+            "steps": args.steps, "warmup": args.warmup, "ramp_up_steps": RAMP_UP_STEPS,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: DynEdge energy regression, synthetic IceCube-86 pulses "
-                                   "(~150/event, 7 features), k=8, fwd+bwd+Adam",
-                       "events_per_gpu": args.events, "pulses_per_gpu": n_nodes, "edges_per_layer": n_edges,
+            "config": {"workload": ("configs[1]: DynEdge energy regression, synthetic IceCube-86 pulses "
+                                    "(~150/event, 7 features), k=8, fwd+bwd+Adam" if world == 1 else
+                                    f"configs[2]: configs[1] as event-batch data parallel over {world} GPUs, "
+                                    "RCCL gradient all-reduce"),
+                       "events_per_gpu": args.events, "global_batch": args.events * world,
+                       "pulses_per_gpu": n_nodes, "edges_per_layer": n_edges,
                        "parallelism": f"dp{world} (event shards, one flat RCCL all-reduce)"},
+            "backend": (dist.get_backend() if world > 1 else None),
+            "allreduce_us_per_step": ar_in_step_us if world > 1 else 0.0,
+            "allreduce_alone_us": ar_alone_us,
+            "allreduce_bytes": int(sync.flat.numel()) * 4,
+            "weights_identical_across_ranks": same_weights,
             "roofline": {"bound": bound, "kernel": kernel_shape or name, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": traffic,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
                          "launch_ms": per_launch_ms, "launches_per_step": lps},
             "group_tflops": {k: flops[k] / (timers[k][1] / prof_steps * 1e-3) / 1e12 for k in flops if k in timers},
-            "path_roofline": {"algorithmic_tflop_per_step": 3.0 * flops_fwd * world / 1e12,
-                              "achieved_tflops": 3.0 * flops_fwd * world * args.steps / dt / 1e12,
-                              "frac_of_peak": 3.0 * flops_fwd * args.steps / dt / 1e12 / peak},
+            # whole step against the MFMA peak, per GPU.  Two prices: the reference formulation's FLOPs (SURVEY.md 8d:
+            # what PyG would execute for the same result) and the FLOPs this path really executes (P|Q split)
+            "path_roofline": {"reference_formulation_tflop_per_step": 3.0 * flops_fwd / 1e12,
+                              "reference_formulation_tflops_equiv": 3.0 * flops_fwd * args.steps / dt / 1e12,
+                              "reference_formulation_frac": 3.0 * flops_fwd * args.steps / dt / 1e12 / peak,
+                              "executed_tflop_per_step": flops_exec / 1e12,
+                              "executed_tflops": flops_exec * args.steps / dt / 1e12,
+                              "executed_frac": flops_exec * args.steps / dt / 1e12 / peak,
+                              "note": "per GPU; executed_frac is the MFMA utilisation of the step"},
             "phase_ms_per_step": {k: v[1] / prof_steps for k, v in sorted(timers.items(), key=lambda kv: -kv[1][1])},
             "launch": launch, "host_issue_ms": host_issue_ms,
             "final_loss": float(loss.detach()),
-            "measured_peaks": measured_peaks(dev),
+            "measured_peaks": (_log("yardsticks: library GEMM, device copy"), measured_peaks(dev))[1],
             "other_batch_size": extra,
+            "fp32": fp32,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_events, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_events, args.cpu_steps, args.cpu_warmup, parity_model=model)
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()                  # rank 0 is still measuring its yardsticks: leave together
         dist.destroy_process_group()

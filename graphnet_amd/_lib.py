@@ -74,13 +74,21 @@ SIGNATURES = {
 
 
 def build(verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into ``libgraphnet_amd.so`` (in-tree)."""
+    """Compile every HIP source for gfx950 into ``libgraphnet_amd.so`` (in-tree).  Serialised by a file lock: N
+    ranks starting on a fresh checkout must not run ``make`` on the same ``build/*.o`` at once - the first one builds,
+    the others wait and find everything up to date."""
+    import fcntl
     cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j", "6"]
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    with open(os.path.join(_HERE, "csrc", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     if verbose or res.returncode != 0:
         print(res.stdout)
     if res.returncode != 0:
-        raise RuntimeError("building libgraphnet_amd.so failed")
+        raise RuntimeError("building libgraphnet_amd.so failed:\n" + res.stdout[-4000:])
     return LIB_PATH
 
 
@@ -90,16 +98,19 @@ def lib() -> ctypes.CDLL:
     if _lib is None:
         if not os.path.exists(LIB_PATH) and os.environ.get("GN_NO_AUTOBUILD") != "1" and \
                 os.path.exists(os.path.join(_HERE, "csrc", "Makefile")):
+            build_error = None
             try:                                    # a checkout without build artefacts: compile once (hipcc, ~1 min)
                 build()
-            except Exception:                       # no hipcc / compile error: reported by the check below
-                pass
+            except Exception as exc:                # no hipcc / compile error: chained into the error below
+                build_error = exc
+        else:
+            build_error = None
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
                 "graphnet_amd has no CPU fallback for device ops."
-            )
+            ) from build_error
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing

@@ -421,23 +421,31 @@ __global__ __launch_bounds__(256) void table_to_edges(const int* __restrict__ nb
     if (ovf && ovf[i] >= 0) { edge_index[e] = ovf[i]; edge_index[E + e] = i; }
 }
 // edges sorted by target (edge_index[1] ascending, as knn_graph emits them): the e-th edge of
-// centre i goes to slot e - first[i]; slot K goes to ovf; deeper slots are counted in *err.
-__global__ __launch_bounds__(256) void edges_first(const long long* __restrict__ dst, long long E, int* __restrict__ first) {
+// centre i goes to slot e - first[i]; slot K goes to ovf.  Nothing is written from an entry that has not been
+// validated: pass 1 range-checks BOTH rows of the int64 input (before any truncation to int) and the order, pass 2
+// does not run at all when pass 1 raised a flag.  *err bits: 1 = an index outside [0, N), 2 = not grouped by
+// ascending target, 4 = an in-degree above K + 1 (the host side re-sorts / re-sizes and calls again).
+__global__ __launch_bounds__(256) void edges_first(const long long* __restrict__ src, const long long* __restrict__ dst,
+                                                   long long E, int N, int* __restrict__ first, int* __restrict__ err) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
-    if (e == 0 || dst[e - 1] != dst[e]) first[dst[e]] = (int)e;
+    const long long d = dst[e], s = src[e];
+    if (d < 0 || d >= N || s < 0 || s >= N) { atomicOr(err, 1); return; }
+    if (e > 0 && dst[e - 1] > d) atomicOr(err, 2);
+    if (e == 0 || dst[e - 1] != d) first[d] = (int)e;             // one writer per target when the order is right
 }
 __global__ __launch_bounds__(256) void edges_to_table(const long long* __restrict__ src, const long long* __restrict__ dst,
                                                       long long E, const int* __restrict__ first, int K,
                                                       int* __restrict__ nbr, int* __restrict__ ovf, int* __restrict__ err) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
+    if ((__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 3) != 0) return;   // pass 1 refused the input
     const int i = (int)dst[e];
-    const int s = (int)(e - first[i]);
-    if (e > 0 && dst[e - 1] > dst[e]) atomicAdd(err, 1);          // not sorted by target
+    const long long s = e - first[i];                              // >= 0: targets ascend and first[i] is i's run start
+    if (s < 0) { atomicOr(err, 2); return; }
     if (s < K) nbr[(long long)i * K + s] = (int)src[e];
     else if (s == K) ovf[i] = (int)src[e];
-    else atomicAdd(err, 1);                                        // degree > K+1
+    else atomicOr(err, 4);                                         // degree > K+1
 }
 
 // ---------------------------------------------------------------- feature standardisation
@@ -763,7 +771,7 @@ hipError_t launch_edges_to_table(const long long* edge_index, long long E, int N
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(err, 0, sizeof(int), st);
     if (e != hipSuccess || E == 0) return e;
-    hipLaunchKernelGGL(edges_first, dim3(cdiv(E, 256)), dim3(256), 0, st, edge_index + E, E, first);
+    hipLaunchKernelGGL(edges_first, dim3(cdiv(E, 256)), dim3(256), 0, st, edge_index, edge_index + E, E, N, first, err);
     hipLaunchKernelGGL(edges_to_table, dim3(cdiv(E, 256)), dim3(256), 0, st, edge_index, edge_index + E, E, first, K, nbr, ovf, err);
     return hipGetLastError();
 }

@@ -105,6 +105,41 @@ class Batch(Data):
         return out
 
 
+def select_events(batch: Batch, events) -> Batch:
+    """The sub-batch holding ``events`` (ascending event ids of ``batch``) - what a ``DistributedSampler`` shard of the
+    same events would have collated: node rows of the kept events, per-event rows, ``edge_index`` relabelled,
+    ``ptr`` / ``batch`` rebuilt.  Works on any device; index arithmetic only."""
+    ptr = batch.ptr.to(torch.int64)
+    dev = ptr.device
+    ev = torch.as_tensor(list(events) if not isinstance(events, Tensor) else events, dtype=torch.int64, device=dev)
+    B, N = int(ptr.shape[0]) - 1, int(ptr[-1])
+    sizes = (ptr[1:] - ptr[:-1])[ev]
+    new_ptr = torch.zeros(ev.numel() + 1, dtype=torch.int64, device=dev)
+    new_ptr[1:] = torch.cumsum(sizes, 0)
+    n_new = int(new_ptr[-1])
+    new_batch = torch.repeat_interleave(torch.arange(ev.numel(), dtype=torch.int64, device=dev), sizes)
+    rows = torch.arange(n_new, dtype=torch.int64, device=dev) - new_ptr[new_batch] + ptr[ev][new_batch]
+    out = Batch()
+    for k, v in batch.items():
+        if k in ("ptr", "batch"):
+            continue
+        if k == "edge_index":
+            new_id = torch.full((N,), -1, dtype=torch.int64, device=dev)
+            new_id[rows] = torch.arange(n_new, dtype=torch.int64, device=dev)
+            keep = new_id[v[1].to(dev)] >= 0                      # edges never leave an event: the target decides
+            out[k] = torch.stack([new_id[v[0].to(dev)[keep]], new_id[v[1].to(dev)[keep]]])
+        elif isinstance(v, Tensor) and v.dim() >= 1 and int(v.shape[0]) == N and N != B:
+            out[k] = v[rows.to(v.device)]
+        elif isinstance(v, Tensor) and v.dim() >= 1 and int(v.shape[0]) == B:
+            out[k] = v[ev.to(v.device)]
+        elif isinstance(v, list) and len(v) == B:
+            out[k] = [v[int(i)] for i in ev]
+        else:
+            out[k] = v
+    out.ptr, out.batch = new_ptr, new_batch
+    return out
+
+
 def collate_fn(graphs: List[Data]) -> Batch:
     """``data/dataloader.py:12-18``: drop events with <= 1 pulse, then batch."""
     graphs = [g for g in graphs if int(g.n_pulses) > 1]

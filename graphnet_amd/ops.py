@@ -225,19 +225,34 @@ def knn_graph(x: Tensor, cols: Sequence[int], batch: Tensor, ptr: Tensor, k: int
 
 
 def table_from_edge_index(edge_index: Tensor, N: int, K: int) -> NeighbourTable:
-    """Loader-supplied ``edge_index`` (sorted by target, degree <= K+1) -> neighbour table."""
+    """Loader-supplied ``edge_index`` -> neighbour table.  PyG's ``EdgeConv`` takes edges in any order and of any
+    in-degree, so this does too: edges that are not grouped by ascending target are stable-sorted by target first,
+    and the table is sized by the largest in-degree when that exceeds ``K + 1`` (a loader graph whose k differs
+    from the backbone's ``nb_neighbours``).  Indices outside ``[0, N)`` raise ``ValueError`` - the device pass
+    validates every entry before it writes anything."""
     _need(edge_index, torch.int64, "edge_index")
+    if edge_index.dim() != 2 or int(edge_index.shape[0]) != 2:
+        raise ValueError("edge_index must be [2, E]")
     edge_index = edge_index.contiguous()
     dev = edge_index.device
     E = int(edge_index.shape[1])
-    nbr = torch.empty((N, K), dtype=torch.int32, device=dev)
-    ovf = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
     first = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
     err = torch.zeros(1, dtype=torch.int32, device=dev)
-    _lib.check(_lib.lib().gn_edge_index_to_table(_p(edge_index), E, N, K, _p(first), _p(nbr), _p(ovf), _p(err), _st()))
-    if int(err.item()) != 0:
-        raise ValueError("edge_index must be grouped by target node (ascending) with in-degree <= K+1")
-    return _finish_table(nbr, ovf[:N] if N else ovf, K)
+    for _ in range(3):
+        nbr = torch.empty((N, K), dtype=torch.int32, device=dev)
+        ovf = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().gn_edge_index_to_table(_p(edge_index), E, N, K, _p(first), _p(nbr), _p(ovf), _p(err), _st()))
+        rc = int(err.item())
+        if rc == 0:
+            return _finish_table(nbr, ovf[:N] if N else ovf, K)
+        if rc & 1:
+            raise ValueError(f"edge_index holds node indices outside [0, {N})")
+        if rc & 2:                               # any order is legal input: group by target, keep the order inside a group
+            order = torch.argsort(edge_index[1], stable=True)
+            edge_index = edge_index[:, order].contiguous()
+        elif rc & 4:                             # in-degree above K + 1: size the table by the graph
+            K = int(torch.bincount(edge_index[1], minlength=max(N, 1)).max().item()) - 1
+    raise RuntimeError("gn_edge_index_to_table: could not build the table")       # pragma: no cover
 
 
 def ptr_to_batch(ptr: Tensor, N: int) -> Tensor:

@@ -9,7 +9,7 @@ last backward kernel.  Works unchanged with the ``gloo`` backend on CPU tensors 
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Sequence
+from typing import Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -82,3 +82,35 @@ def shard_events_by_pulses(n_pulses: Sequence[int], world_size: int) -> List[Lis
     for s in shards:
         s.sort()
     return shards
+
+
+def shard_batch_by_pulses(batch, rank: Optional[int] = None, world_size: Optional[int] = None):
+    """This rank's share of a GLOBAL batch that every rank holds (same loader, same order on all ranks): events are
+    dealt to ranks by :func:`shard_events_by_pulses` (deterministic, so the shards are disjoint and cover the batch
+    without any communication), balancing the pulses per rank because the cost of a step is ~ pulses, not events
+    (the reference's length-matched sampler, ``data/dataset/samplers.py:160-292``)."""
+    from .data import select_events
+    if rank is None:
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world_size == 1:
+        return batch
+    n = batch.n_pulses.detach().cpu().tolist()
+    return select_events(batch, shard_events_by_pulses(n, world_size)[rank])
+
+
+def check_equal_steps(n_steps: int, group=None) -> None:
+    """Every step ends in a collective: ranks whose loaders disagree in length would hang in it.  One MIN/MAX
+    all-reduce up front turns that into an error."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    t = torch.tensor([n_steps, -n_steps], dtype=torch.int64)
+    backend = dist.get_backend(group)
+    if backend == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    lo, hi = int(t[0]), -int(t[1])
+    if lo != hi:
+        raise RuntimeError(f"ranks disagree on the number of steps per epoch ({lo} .. {hi}): the gradient "
+                           f"all-reduce would hang; give every rank the same number of batches")

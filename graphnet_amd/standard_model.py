@@ -433,7 +433,7 @@ class StandardModel(Model):
             max_epochs: int = 10, early_stopping_patience: int = 5, ckpt_path: Optional[str] = None,
             log_every_n_steps: int = 1, gradient_clip_val: Optional[float] = None, default_root_dir: Optional[str] = None,
             save_dir: Optional[str] = None, device: str = "cuda",
-            grad_sync: Optional[Callable[[], None]] = None) -> Dict[str, List[float]]:
+            grad_sync: Optional[Callable[[], None]] = None, shard_by_pulses: bool = False) -> Dict[str, List[float]]:
         """The training loop ``EasySyntax.fit`` hands to ``pytorch_lightning.Trainer`` (``easy_model.py:83-184``), written
         out: per step forward + loss + backward + optional gradient all-reduce (``grad_sync``, e.g.
         ``FlatGradAllReduce.__call__``; created automatically when ``torch.distributed`` is initialised) + optional
@@ -443,7 +443,12 @@ class StandardModel(Model):
         whose weights are loaded back at the end (``l.177-184``).  ``ckpt_path`` resumes weights, optimizer state and the
         epoch counter.  ``save_dir`` adds what ``GraphnetEarlyStopping`` (``training/callbacks.py:163-249``) writes:
         ``config.yml`` at the start and ``best_model.pth`` (plain state dict) at every improvement.  Ctrl-C leaves the
-        loop gracefully.  Returns (and keeps in ``self.history``) the logged series
+        loop gracefully.  Under an initialised process group (one process per GPU) the replicas are made identical
+        first (parameters and buffers broadcast from rank 0, as Lightning's DDP does at start), the loaders' lengths
+        are checked to agree (every step ends in the all-reduce), and with ``shard_by_pulses=True`` every rank is
+        handed the same GLOBAL batches and keeps its pulse-balanced share of each
+        (``parallel.shard_batch_by_pulses``); otherwise the loaders are expected to be sharded already (a
+        ``DistributedSampler``).  Returns (and keeps in ``self.history``) the logged series
         ``train_loss`` / ``val_loss`` per epoch and ``lr`` every ``log_every_n_steps`` steps."""
         import torch.distributed as dist
         self.to(device)
@@ -458,9 +463,14 @@ class StandardModel(Model):
                 scheduler.load_state_dict(rest["lr_schedulers"][0])
             start_epoch, step = int(rest.get("epoch", -1)) + 1, int(rest.get("global_step", 0))
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        if grad_sync is None and distributed:
-            from .parallel import FlatGradAllReduce
-            grad_sync = FlatGradAllReduce(self.parameters())
+        if distributed:
+            from . import parallel
+            parallel.broadcast_parameters(self)                   # after ckpt_path loading, before the first step
+            parallel.check_equal_steps(len(train_dataloader))
+            if val_dataloader is not None:
+                parallel.check_equal_steps(len(val_dataloader))
+            if grad_sync is None:
+                grad_sync = parallel.FlatGradAllReduce(self.parameters())
         zero = grad_sync.zero_grad if hasattr(grad_sync, "zero_grad") else (lambda: optimizer.zero_grad(set_to_none=True))
         rank0 = not distributed or dist.get_rank() == 0
         history: Dict[str, List[float]] = {"train_loss": [], "val_loss": [], "lr": []}
@@ -475,6 +485,10 @@ class StandardModel(Model):
             nonlocal step
             total, count = None, 0
             for i, batch in enumerate(loader):
+                if shard_by_pulses and distributed:
+                    from .parallel import shard_batch_by_pulses
+                    batch = shard_batch_by_pulses(batch) if isinstance(batch, Data) else \
+                        [shard_batch_by_pulses(b) for b in batch]
                 batch = batch.to(device) if isinstance(batch, Data) else [b.to(device) for b in batch]
                 if training:
                     zero()

@@ -79,6 +79,10 @@ int gn_rev_build_events(const int32_t* nbr, int32_t N, int32_t K, const int32_t*
 int gn_table_degree(const int32_t* nbr, const int32_t* ovf, int32_t N, int32_t K, int32_t* deg, void* stream);
 int gn_table_to_edge_index(const int32_t* nbr, const int32_t* ovf, int32_t N, int32_t K, const int32_t* off,
                            int64_t E, int64_t* edge_index, void* stream);
+/* gn_edge_index_to_table validates before it writes: *err (device int) comes back 0, or a mask of 1 = an index
+ * outside [0, N) in either row, 2 = targets not ascending, 4 = an in-degree above K + 1; with bit 1 or 2 set the
+ * table is left untouched (all -1).  The host side (ops.table_from_edge_index) sorts / re-sizes and calls again,
+ * because PyG's EdgeConv (components/layers.py:60) accepts any edge order and degree. */
 int gn_edge_index_to_table(const int64_t* edge_index, int64_t E, int32_t N, int32_t K, int32_t* first_N,
                            int32_t* nbr, int32_t* ovf, int32_t* err, void* stream);
 

@@ -1,0 +1,58 @@
+"""bench.py as the driver calls it: ``python bench.py --gpus N`` must start N ranks itself (configs[2]; the reference
+gets its ranks from Lightning's ``Trainer(strategy="ddp", devices=gpus)``, ``models/easy_model.py:83-112``).
+CPU only: ``--dry-run`` keeps the launcher, the rendezvous, the flat all-reduce and the config-3 report fields and
+replaces the HIP model by a stand-in network over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=300):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=timeout)
+
+
+def test_gpus_2_starts_two_ranks_and_reports_config3_facts():
+    r = _run(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                     # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["backend"] == "gloo" and out["dry_run"] is True
+    assert out["weights_identical_across_ranks"] is True
+    assert out["allreduce_us_per_step"] > 0.0
+    assert out["value"] is None                          # a dry run never reports a throughput
+
+
+def test_single_rank_dry_run():
+    r = _run(["--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip())
+    assert out["n_gpus"] == 1 and out["weights_identical_across_ranks"] is True
+
+
+def test_world_size_mismatch_is_refused():
+    r = _run(["--gpus", "2", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr and r.stdout.strip() == ""
+
+
+def test_more_gpus_than_devices_is_refused_before_any_rank_starts():
+    import torch
+    if torch.cuda.device_count() >= 6:                   # a full node: nothing to refuse
+        return
+    r = _run(["--gpus", "6", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 2 and "GPU(s) are visible" in r.stderr and r.stdout.strip() == ""
+
+
+def test_failing_rank_fails_the_job():
+    # rank 1 cannot join (its MASTER_PORT is overridden to a dead port through the per-rank hook): the launcher must
+    # not hang on rank 0 and must exit non-zero
+    r = _run(["--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"], env={"GN_BENCH_TEST_FAIL_RANK": "1"},
+             timeout=120)
+    assert r.returncode != 0

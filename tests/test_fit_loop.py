@@ -27,8 +27,8 @@ class _MeanBackbone(g.GNN):
         return torch.relu(self.lin(s / data.n_pulses.clamp_min(1).unsqueeze(1).float()))
 
 
-def _model(lr: float, **kw):
-    torch.manual_seed(0)
+def _model(lr: float, seed: int = 0, **kw):
+    torch.manual_seed(seed)
     return g.StandardModel(graph_definition=g.KNNGraph(g.IceCube86()), backbone=_MeanBackbone(),
                            tasks=[g.EnergyReconstruction(hidden_size=16, loss_function=g.LogCoshLoss(),
                                                          transform_prediction_and_target=torch.log10)],
@@ -112,11 +112,9 @@ def _free_port():
 def _worker(rank, world, port, root, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from graphnet_amd.parallel import broadcast_parameters
     train = [synthetic_icecube86_batch(6, seed=10 * rank + s) for s in (1, 2)]     # disjoint event shards
     val = [synthetic_icecube86_batch(4 + rank, seed=50 + rank)]
-    m = _model(lr=2e-2)
-    broadcast_parameters(m)
+    m = _model(lr=2e-2, seed=rank)                         # different initial weights: fit itself must broadcast them
     hist = m.fit(train, val, max_epochs=3, early_stopping_patience=3, default_root_dir=root, device="cpu")
     flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
     q.put((rank, flat.numpy().copy(), hist, m.best_model_path))
@@ -137,3 +135,64 @@ def test_fit_world2_gloo_ranks_agree(tmp_path):
     assert np.array_equal(res[0][1], res[1][1]), "weights after fit must be identical on every rank"
     assert res[0][2]["train_loss"] == res[1][2]["train_loss"] and res[0][2]["val_loss"] == res[1][2]["val_loss"]
     assert res[0][3] == res[1][3] and len(os.listdir(tmp_path / "checkpoints")) == 1
+
+
+def _worker_sharded(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from graphnet_amd.parallel import shard_batch_by_pulses
+    train = [synthetic_icecube86_batch(9, seed=s) for s in (1, 2)]                  # the SAME global batches on every rank
+    mine = [shard_batch_by_pulses(b) for b in train]
+    m = _model(lr=2e-2, seed=rank)
+    hist = m.fit(train, max_epochs=2, device="cpu", shard_by_pulses=True)
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    q.put((rank, flat.numpy().copy(), hist, [b.energy.numpy().copy() for b in mine],
+           [int(b.x.shape[0]) for b in mine]))
+    if rank == 1:                                          # loaders of different length must raise, not hang
+        train = train[:1]
+    try:
+        _model(lr=1e-2).fit(train, max_epochs=1, device="cpu")
+        q.put((rank, "no error"))
+    except RuntimeError as exc:
+        q.put((rank, str(exc)))
+    dist.destroy_process_group()
+
+
+def test_fit_world2_shards_global_batches_by_pulses(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(2 * world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res = sorted([t for t in got if len(t) == 5], key=lambda t: t[0])
+    errs = [t for t in got if len(t) == 2]
+    assert np.array_equal(res[0][1], res[1][1])
+    assert res[0][2]["train_loss"] == res[1][2]["train_loss"]
+    for s, seed in enumerate((1, 2)):                      # the shards are disjoint, cover the batch, balance the pulses
+        full = synthetic_icecube86_batch(9, seed=seed)
+        both = np.sort(np.concatenate([res[0][3][s], res[1][3][s]]))
+        assert np.array_equal(both, np.sort(full.energy.numpy()))
+        n0, n1 = res[0][4][s], res[1][4][s]
+        assert n0 + n1 == int(full.x.shape[0]) and abs(n0 - n1) <= int(full.n_pulses.max())
+    assert all("disagree on the number of steps" in e[1] for e in errs), errs
+
+
+def test_select_events_equals_collating_those_events():
+    from graphnet_amd.data import Batch, Data, select_events
+    rng = np.random.default_rng(3)
+    graphs = []
+    for b in range(6):
+        n = int(rng.integers(2, 9))
+        ei = torch.tensor([[(i + 1) % n for i in range(n)], list(range(n))], dtype=torch.int64)
+        graphs.append(Data(x=torch.randn(n, 4), edge_index=ei, n_pulses=torch.tensor(n, dtype=torch.int32),
+                           energy=torch.tensor(float(b)), w=torch.full((1, 1), float(b))))
+    full = Batch.from_data_list(graphs)
+    keep = [1, 2, 5]
+    sub, ref = select_events(full, keep), Batch.from_data_list([graphs[i] for i in keep])
+    for k in ("x", "edge_index", "n_pulses", "energy", "w", "ptr", "batch"):
+        assert torch.equal(sub[k], ref[k]), k

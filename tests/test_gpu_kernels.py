@@ -82,6 +82,41 @@ def test_knn_reference_events_and_edge_index(oracle, golden):
                 _cmp_table(t2, exp, 8)
 
 
+def test_loader_edge_index_any_order_any_degree_and_bad_indices(oracle):
+    """PyG's EdgeConv (``components/layers.py:60``) takes edges in any order and with any in-degree; indices outside
+    [0, N) are the caller's error.  The device pass validates both int64 rows before it writes anything."""
+    from graphnet_amd import ops
+    b = _batch(10, seed=21)
+    N = int(b.x.shape[0])
+    ei = oracle.knn_graph(b.x, 8, b.batch, [0, 1, 2])                       # grouped by target
+    t_sorted = ops.table_from_edge_index(ei.to(DEV), N, 8)
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(0))
+    t_shuf = ops.table_from_edge_index(ei[:, perm].to(DEV), N, 8)           # any order: same neighbour SETS per target
+
+    def rows(t):
+        full = torch.cat([t.nbr.cpu(), t.ovf.cpu().unsqueeze(1)], dim=1)
+        return torch.sort(full, dim=1).values
+    assert torch.equal(rows(t_sorted), rows(t_shuf))
+    # the shuffled table keeps, inside a target, the order the edges had in the input (stable grouping)
+    order = torch.argsort(ei[1, perm], stable=True)
+    again = ops.table_from_edge_index(ei[:, perm][:, order].to(DEV), N, 8)
+    assert torch.equal(again.nbr, t_shuf.nbr) and torch.equal(again.ovf, t_shuf.ovf)
+    # a loader graph with another k (here 12) than the backbone's nb_neighbours = 8: the table grows
+    ei12 = oracle.knn_graph(b.x, 12, b.batch, [0, 1, 2])
+    t12 = ops.table_from_edge_index(ei12.to(DEV), N, 8)
+    assert t12.K >= 11 and torch.equal(t12.edge_index().cpu(), ei12)
+    # out-of-range entries in either row, negative or too large, also beyond int32: ValueError, nothing written OOB
+    for row, val in ((0, N), (1, N), (0, -1), (1, -5), (1, 2 ** 33 + 3), (0, 2 ** 40)):
+        bad = ei.clone()
+        bad[row, 17] = val
+        with pytest.raises(ValueError):
+            ops.table_from_edge_index(bad.to(DEV), N, 8)
+    with pytest.raises(ValueError):
+        ops.table_from_edge_index(torch.zeros((3, 4), dtype=torch.int64, device=DEV), N, 8)
+    # and the device is still healthy: the valid input still converts
+    assert torch.equal(ops.table_from_edge_index(ei.to(DEV), N, 8).nbr, t_sorted.nbr)
+
+
 def test_knn_edge_cases(oracle):
     from graphnet_amd import ops
     # ragged: events of 1, 2, 3 nodes (degree n-1), > k duplicates, D = 4 columns, big event
@@ -171,29 +206,50 @@ def test_dq_gather_hub_nodes(oracle, name, mode):
     assert rel_err(dQ, ref) < (1e-5 if mode == 0 else 1e-2)
 
 
-def test_standardize_on_device_matches_host(oracle):
-    """Detector._standardize as one HIP kernel: every non-log column bit-identical to the host expression
-    (they decide the k-NN graph), log10 columns to fp32 rounding of the device libm."""
+def test_standardize_on_device_matches_oracle(oracle):
+    """Detector._standardize as one HIP kernel against the ORACLE's restatement of the reference lambdas
+    (oracle/detector_oracle.py; detector.py:64-77, icecube.py:21-48,84-170, prometheus.py:11-39): every non-log column
+    bit-identical (they decide the k-NN graph), log10 columns to fp32 rounding of the device libm.  Also on the
+    reference's own bundled events (the inputs of the golden k-NN tables)."""
     import graphnet_amd as g
+    from oracle import detector_oracle as det_orc
     rng = np.random.default_rng(3)
-    for det, names in ((g.IceCube86(), ["dom_x", "dom_y", "dom_z", "dom_time", "charge", "rde", "pmt_area"]),
-                       (g.IceCubeDeepCore(), ["dom_x", "dom_y", "dom_z", "dom_time", "charge", "rde", "pmt_area", "hlc"]),
-                       (g.IceCubeUpgrade(), ["dom_x", "dom_y", "dom_z", "dom_time", "charge", "rde", "pmt_area", "string",
-                                             "pmt_number", "dom_number", "pmt_dir_x", "pmt_dir_y", "pmt_dir_z", "dom_type"]),
-                       (g.Prometheus(), ["sensor_pos_x", "sensor_pos_y", "sensor_pos_z", "t"])):
+    cases = (("IceCube86", g.IceCube86(), ["dom_x", "dom_y", "dom_z", "dom_time", "charge", "rde", "pmt_area"]),
+             ("IceCubeDeepCore", g.IceCubeDeepCore(), ["dom_x", "dom_y", "dom_z", "dom_time", "charge", "rde", "pmt_area", "hlc"]),
+             ("IceCubeUpgrade", g.IceCubeUpgrade(), ["dom_x", "dom_y", "dom_z", "dom_time", "charge", "rde", "pmt_area", "string",
+                                                     "pmt_number", "dom_number", "pmt_dir_x", "pmt_dir_y", "pmt_dir_z", "dom_type"]),
+             ("Prometheus", g.Prometheus(), ["sensor_pos_x", "sensor_pos_y", "sensor_pos_z", "t"]))
+    log_cols = {"IceCube86": {"charge"}, "IceCubeDeepCore": set(), "IceCubeUpgrade": {"charge"}, "Prometheus": set()}
+    for name, det, names in cases:
         F = len(names)
         raw = torch.from_numpy(rng.uniform(-600, 600, size=(1000, F)).astype(np.float32))
         if "charge" in names:
             raw[:, names.index("charge")] = torch.from_numpy(rng.lognormal(0.3, 0.9, 1000).astype(np.float32))
-        host = det(raw.clone(), names)
+        want = det_orc.standardize(name, raw, names)
         dev = det(raw.clone().to(DEV), names).cpu()
         for f, nm in enumerate(names):
-            if any(op == "log10" for op, _ in det.feature_ops()[nm]):
-                assert torch.allclose(dev[:, f], host[:, f], rtol=2e-6, atol=1e-7), nm
+            if nm in log_cols[name]:
+                assert torch.allclose(dev[:, f], want[:, f], rtol=2e-6, atol=1e-7), (name, nm)
             else:
-                assert torch.equal(dev[:, f], host[:, f]), nm
+                assert torch.equal(dev[:, f], want[:, f]), (name, nm)
     with pytest.raises(KeyError):
         g.IceCube86()(raw.to(DEV), ["nope"] * F)
+
+
+def test_standardize_reference_events_equal_golden_xstd(golden):
+    """The reference's bundled events through gn_standardize == the *_xstd fixture (generated by the oracle's Detector
+    restatement, tests/golden/make_fixtures.py), xyz columns bit for bit: the golden k-NN tables start from them."""
+    import graphnet_amd as g
+    ev, ex = golden["reference_events"], golden["oracle_expected"]
+    ice = ["dom_x", "dom_y", "dom_z", "dom_time", "charge", "rde", "pmt_area"]
+    upg = ice + ["string", "pmt_number", "dom_number", "pmt_dir_x", "pmt_dir_y", "pmt_dir_z", "dom_type"]
+    for name, det, names in (("deepcore", g.IceCube86(), ice), ("upgrade", g.IceCubeUpgrade(), upg),
+                             ("prometheus", g.Prometheus(), ["sensor_pos_x", "sensor_pos_y", "sensor_pos_z", "t"])):
+        raw = torch.tensor(ev[f"{name}_x"], dtype=torch.float32)
+        dev = det(raw.to(DEV), names).cpu()
+        want = torch.from_numpy(ex[f"{name}_xstd"])
+        assert torch.equal(dev[:, :3], want[:, :3]), name
+        assert torch.allclose(dev, want, rtol=2e-6, atol=1e-7), name
 
 
 # ------------------------------------------------------------------------------ globals

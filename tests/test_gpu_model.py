@@ -24,6 +24,20 @@ def norm_err(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
+def _parity_report(name, values):
+    """Measured parity numbers, written where the GPU run keeps them (gpurun_out/ is merged back): the gates are in
+    the asserts, this is the record of how far inside them each tensor is."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_report.jsonl"), "a") as fh:
+            fh.write(json.dumps({"test": name, "max": max(values.values()) if values else None, "values": values}) + "\n")
+    except OSError:
+        pass
+
+
 def _pair(oracle, F=7, seed=20241016, **kw):
     import graphnet_amd as g
     torch.manual_seed(seed)
@@ -74,6 +88,13 @@ def test_full_model_teacher_forced(oracle, dtype, tol, gtol):
     assert rel_err(pred, pred_o.detach()) < tol
     assert abs(float(loss) - float(loss_o)) / abs(float(loss_o)) < tol
     go = dict(ref.named_parameters())
+    _parity_report(f"teacher_forced_{dtype}_activations_max_rel",
+                   {**{f"conv_out[{l}]": rel_err(trace["conv_out"][l][:, :tr_o["conv_out"][l].shape[1]],
+                                                  tr_o["conv_out"][l].detach()) for l in range(5)},
+                    "post": rel_err(trace["post"], tr_o["post"].detach()), "latent": rel_err(latent, lat_o.detach()),
+                    "pred": rel_err(pred, pred_o.detach())})
+    _parity_report(f"teacher_forced_{dtype}_grads_max_rel", {k: rel_err(p.grad, go[k].grad) for k, p in m.named_parameters()})
+    _parity_report(f"teacher_forced_{dtype}_grads_frobenius", {k: norm_err(p.grad, go[k].grad) for k, p in m.named_parameters()})
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         # bf16: gate on the Frobenius-norm error (single relu gates may flip); fp32: max-abs
@@ -109,10 +130,16 @@ def test_config1_prometheus_batch2_against_golden(oracle, golden):
     m.backbone.set_backend(dtype="fp32")
     loss = m.shared_step(b.to(DEV))
     loss.backward()
-    assert abs(float(loss) - float(ex["prometheus_model_loss"])) / abs(float(ex["prometheus_model_loss"])) < 1e-3
+    # north_star: fp32 task outputs within 1e-4 rel; SURVEY.md 8d: gradients within 1e-3 rel (sum-order differences).
+    # Free-running: the HIP path re-clusters on its own latent coordinates, the fixture on the oracle's.
+    assert abs(float(loss) - float(ex["prometheus_model_loss"])) / abs(float(ex["prometheus_model_loss"])) < 1e-4
+    report = {}
     for k, p in m.named_parameters():
-        gn = float(ex[f"prometheus_gradnorm::{k}"])
-        assert abs(float(p.grad.double().norm()) - gn) <= 5e-3 * max(gn, 1e-6), k
+        want = torch.from_numpy(ex[f"prometheus_grad::{k}"])              # the full gradient tensor
+        report[k] = rel_err(p.grad, want)
+    _parity_report("config1_prometheus_fp32_grads", report)
+    bad = {k: v for k, v in report.items() if v >= 1e-3}
+    assert not bad, bad
 
 
 def test_training_step_decreases_loss_and_is_reproducible():

@@ -77,6 +77,30 @@ def test_detector_standardisation_and_graph_definition():
     assert torch.equal(a.x, b.x) and not torch.equal(a.x, d.x)
 
 
+def test_detector_host_path_equals_oracle_restatement(golden):
+    """graphnet_amd.detector (op programs, shared with gn_standardize) against oracle/detector_oracle.py (the
+    reference's lambdas written out: detector.py:64-77, icecube.py:21-48,84-170, prometheus.py:11-39), bit for bit on the
+    reference's bundled events and on random columns; the *_xstd fixture is the oracle's output."""
+    from oracle import detector_oracle as det_orc
+    ev, ex = golden["reference_events"], golden["oracle_expected"]
+    ice = FEATURES_ICECUBE86
+    upg = ice + ["string", "pmt_number", "dom_number", "pmt_dir_x", "pmt_dir_y", "pmt_dir_z", "dom_type"]
+    for name, oname, det, names in (("deepcore", "IceCube86", g.IceCube86(), ice),
+                                    ("upgrade", "IceCubeUpgrade", g.IceCubeUpgrade(), upg),
+                                    ("prometheus", "Prometheus", g.Prometheus(),
+                                     ["sensor_pos_x", "sensor_pos_y", "sensor_pos_z", "t"])):
+        raw = torch.tensor(ev[f"{name}_x"], dtype=torch.float32)
+        want = det_orc.standardize(oname, raw, names)
+        assert torch.equal(det(raw.clone(), names), want), name
+        assert torch.equal(want, torch.from_numpy(ex[f"{name}_xstd"])), name      # the committed fixture is the oracle's
+    torch.manual_seed(1)
+    x = (torch.rand(300, 8) * 1200.0 - 600.0).to(torch.float32)
+    names = ice + ["hlc"]
+    assert torch.equal(g.IceCubeDeepCore()(x.clone(), names), det_orc.standardize("IceCubeDeepCore", x, names))
+    with pytest.raises(KeyError):
+        det_orc.standardize("IceCube86", x[:, :1], ["not_a_feature"])
+
+
 def test_detector_programs_equal_the_reference_expressions():
     """Every per-column op program (shared by the host path and the gn_standardize kernel) reproduces the
     reference's lambda bit for bit (icecube.py:21-48,116-170; prometheus.py:11-39)."""
