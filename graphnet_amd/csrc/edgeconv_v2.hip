@@ -550,29 +550,45 @@ __global__ __launch_bounds__(WS_THREADS) void edge_fwd_ws_kernel(
     f32x16 accP;                                     // rows 32-63 of the previous tile, epilogue pending
     zero_acc(accP);
     unsigned int vrowP = 0;
-    bool fastP = false;                              // wave-uniform: every row of that block valid
+    bool fastP = true;                               // wave-uniform: every row of the pending block is valid
     int buf = 0;
     for (; tile < tile_end; ++tile, buf ^= 1) {
         if (wave_on) {
             const unsigned long long vbits = __ballot(s_jc[buf][lane] >= 0);      // bit = tile row valid
-            const unsigned int vrow0 = (unsigned int)(vbits >> (4 * h));
-            const unsigned int vrow1 = (unsigned int)(vbits >> (32 + 4 * h));
             const unsigned char* a0 = &As[buf][r * ROWB + h * 16];
-            f32x16 acc0, acc1;
-            float sumP[2], sum0[2];
-            unsigned int mskP, msk0;
-            if (fastP)
-                fwd_phase<KUSE, S, true>(a0, w2, bias, acc0, accP, vrowP, h, sumP, mskP);
-            else
-                fwd_phase<KUSE, S, false>(a0, w2, bias, acc0, accP, vrowP, h, sumP, mskP);
-            if ((unsigned int)vbits == 0xffffffffu)
-                fwd_phase<KUSE, S, true>(a0 + 32 * ROWB, w2, bias, acc1, acc0, vrow0, h, sum0, msk0);
-            else
-                fwd_phase<KUSE, S, false>(a0 + 32 * ROWB, w2, bias, acc1, acc0, vrow0, h, sum0, msk0);
-            if (tile > tile0) GN_WS_STORE(tile - 1, 1, sumP, mskP);
-            GN_WS_STORE(tile, 0, sum0, msk0);
+            f32x16 acc1;
+            // Rows are invalid only in events of fewer than 9 pulses and in the last tile: two code paths, the hot
+            // one without any per-element validity select, the rare one plain (chain, then epilogue).
+            if (fastP && (unsigned int)vbits == 0xffffffffu) {
+                f32x16 acc0;
+                float sumP[2], sum0[2];
+                unsigned int mskP, msk0;
+                fwd_phase<KUSE, S, true>(a0, w2, bias, acc0, accP, 0u, h, sumP, mskP);
+                // consumer waves issue no global loads: their stores go out at once (nothing of theirs waits on vmcnt)
+                if (tile > tile0) GN_WS_STORE(tile - 1, 1, sumP, mskP);
+                fwd_phase<KUSE, S, true>(a0 + 32 * ROWB, w2, bias, acc1, acc0, 0u, h, sum0, msk0);
+                GN_WS_STORE(tile, 0, sum0, msk0);
+            } else {
+                float ssum[2];
+                unsigned int smsk;
+                if (tile > tile0) {
+                    fwd_epi_block<S, false>(accP, bias, vrowP, h, ssum, smsk);
+                    GN_WS_STORE(tile - 1, 1, ssum, smsk);
+                }
+                f32x16 acc0;
+                zero_acc(acc0);
+#pragma unroll
+                for (int s = 0; s < KUSE; ++s)
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(a0 + s * 32), w2[s], acc0, 0, 0, 0);
+                fwd_epi_block<S, false>(acc0, bias, (unsigned int)(vbits >> (4 * h)), h, ssum, smsk);
+                GN_WS_STORE(tile, 0, ssum, smsk);
+                zero_acc(acc1);
+#pragma unroll
+                for (int s = 0; s < KUSE; ++s)
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(a0 + 32 * ROWB + s * 32), w2[s], acc1, 0, 0, 0);
+            }
             accP = acc1;
-            vrowP = vrow1;
+            vrowP = (unsigned int)(vbits >> (32 + 4 * h));
             fastP = (unsigned int)(vbits >> 32) == 0xffffffffu;
         }
         __syncthreads();

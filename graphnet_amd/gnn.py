@@ -17,16 +17,21 @@ import torch
 from torch import Tensor
 
 from . import ops
-from .model import Model
+from .model import REFERENCE, Model
 
 GLOBAL_POOLINGS = ("min", "max", "sum", "mean")
 
 
-class GNN(Model):
-    """Base class for all core GNN models (``models/gnn/gnn.py:11-35``)."""
+class GNN(*((Model, REFERENCE["GNN"]) if REFERENCE else (Model,))):
+    """Base class for all core GNN models (``models/gnn/gnn.py:11-35``).  When the reference is importable this class
+    also derives from ``graphnet.models.gnn.gnn.GNN``, so a ``graphnet_amd.DynEdge`` passes the reference's
+    ``isinstance(backbone, Model)`` check (``models/standard_model.py:64``) and is captured by its config metaclass."""
 
     def __init__(self, nb_inputs: int, nb_outputs: int) -> None:
-        super().__init__()
+        if REFERENCE:
+            super().__init__(nb_inputs, nb_outputs)       # -> graphnet.models.gnn.gnn.GNN.__init__ (gnn.py:14-21)
+        else:
+            super().__init__()
         self._nb_inputs = nb_inputs
         self._nb_outputs = nb_outputs
 

@@ -9,13 +9,36 @@ accept paths or dicts and rename legacy ``_gnn.`` keys to ``backbone.`` (``model
 from __future__ import annotations
 
 import inspect
+import os
 from collections import OrderedDict
-from typing import Any, Dict, Union
+from typing import Any, Dict, Optional, Union
 
 import torch
 import yaml
 
 _REGISTRY: Dict[str, type] = {}
+
+
+def _find_reference() -> Optional[Dict[str, type]]:
+    """The reference's own base classes, when ``graphnet`` is importable in this interpreter (it is not in the build
+    image: it needs pytorch-lightning / torch-geometric).  ``graphnet.models.StandardModel`` asserts
+    ``isinstance(backbone, Model)`` (``models/standard_model.py:64``) and captures configs through the metaclass of
+    ``Model`` (``utilities/config/model_config.py:317-346``), so for ``StandardModel(backbone=graphnet_amd.DynEdge(...))``
+    to work there, ``graphnet_amd.Model`` / ``GNN`` must BE subclasses of theirs.  ``GRAPHNET_AMD_NO_REFERENCE=1``
+    keeps the stand-alone tree."""
+    if os.environ.get("GRAPHNET_AMD_NO_REFERENCE") == "1":
+        return None
+    try:
+        from graphnet.models import Model as ref_model
+        from graphnet.models.gnn.gnn import GNN as ref_gnn
+    except Exception:                      # not installed, or one of its own dependencies is missing
+        return None
+    if not (isinstance(ref_model, type) and issubclass(ref_model, torch.nn.Module) and issubclass(ref_gnn, ref_model)):
+        return None
+    return {"Model": ref_model, "GNN": ref_gnn}
+
+
+REFERENCE = _find_reference()
 
 
 # Strings the reference's YAML uses for things YAML cannot hold (``utilities/config/parsing.py``): classes as
@@ -62,7 +85,7 @@ def _parse_special_string(v: str) -> Any:
 
 def _to_config_value(v: Any) -> Any:
     if isinstance(v, Model):
-        return {"ModelConfig": v.config.as_dict()}
+        return {"ModelConfig": v.amd_config.as_dict()}
     if isinstance(v, (list, tuple)):
         return [_to_config_value(i) for i in v]
     if isinstance(v, slice):
@@ -135,8 +158,10 @@ class ModelConfig:
         return klass(**args)
 
 
-class _ConfigSaverMeta(type):
-    """Captures the actual constructor call + defaults (``model_config.py:317-346``)."""
+class _ConfigSaverMeta(type(REFERENCE["Model"]) if REFERENCE else type):
+    """Captures the actual constructor call + defaults (``model_config.py:317-346``).  With the reference importable
+    this metaclass derives from the reference's (``ModelConfigSaverABC``), whose ``__call__`` runs first and stores ITS
+    ``ModelConfig`` in ``_config``; ours is kept beside it in ``_amd_config``."""
 
     def __call__(cls, *args: Any, **kwargs: Any) -> Any:
         obj = super().__call__(*args, **kwargs)
@@ -152,23 +177,33 @@ class _ConfigSaverMeta(type):
                     arguments.update(bound.arguments[n])
         except TypeError:
             arguments = OrderedDict(kwargs)
-        obj._config = ModelConfig(cls.__name__, dict(arguments))
+        obj._amd_config = ModelConfig(cls.__name__, dict(arguments))
+        if REFERENCE is None:
+            obj._config = obj._amd_config
         return obj
 
-    def __init__(cls, name, bases, ns):
-        super().__init__(name, bases, ns)
+    def __init__(cls, name, bases, ns, **kw):
+        super().__init__(name, bases, ns, **kw)
         _REGISTRY[name] = cls
 
 
-class Model(torch.nn.Module, metaclass=_ConfigSaverMeta):
-    """Base class for all components (``models/model.py:20``)."""
+class Model(*((REFERENCE["Model"],) if REFERENCE else (torch.nn.Module,)), metaclass=_ConfigSaverMeta):
+    """Base class for all components (``models/model.py:20``).  A subclass of the reference's ``Model`` whenever that
+    one can be imported (see :func:`_find_reference`), of ``torch.nn.Module`` otherwise."""
 
     @property
-    def config(self) -> ModelConfig:
+    def amd_config(self) -> ModelConfig:
+        """This package's ``ModelConfig`` (safe YAML, nothing evaluated on load)."""
+        return self._amd_config
+
+    @property
+    def config(self) -> Any:
+        """The captured constructor call: the reference's ``ModelConfig`` object when the reference is importable (so
+        that its ``StandardModel`` can nest and dump it), this package's otherwise."""
         return self._config
 
     def save_config(self, path: str) -> None:
-        self._config.dump(path)
+        self._amd_config.dump(path)
 
     @classmethod
     def from_config(cls, source: Union[ModelConfig, str]) -> "Model":
@@ -185,5 +220,5 @@ class Model(torch.nn.Module, metaclass=_ConfigSaverMeta):
         state_dict = torch.load(path, weights_only=True) if isinstance(path, str) else path
         state_dict = OrderedDict(
             (("backbone." + k[len("_gnn."):]) if k.startswith("_gnn.") else k, v) for k, v in state_dict.items())
-        super().load_state_dict(state_dict, **kargs)
+        torch.nn.Module.load_state_dict(self, state_dict, **kargs)
         return self

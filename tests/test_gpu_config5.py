@@ -1,0 +1,150 @@
+"""BASELINE configs[4]: high-energy tracks (~10^4 pulses per event), k = 16, four DynEdgeConv layers - the
+scatter / segmented-reduce stress case (reference: ``models/gnn/dynedge.py:295-349`` with ``nb_neighbours=16``;
+``models/components/layers.py:55-69``).  Exercises what configs[1] never reaches: the S = 16 slot kernels, the
+8-wave k-NN with list merging on every tile, hub lists (hundreds of pulses per DOM), the global reverse-adjacency
+build (fewer than 64 events) and 16-bit slot masks."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def norm_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _d2(x, i, j):
+    dx = x[j, 0] - x[i, 0]; dy = x[j, 1] - x[i, 1]; dz = x[j, 2] - x[i, 2]
+    return (dx * dx + dy * dy) + dz * dz
+
+
+def test_knn_k16_on_full_size_tracks_bit_exact(oracle):
+    """k-NN, k = 16, on a B = 4 batch of ~10^4-pulse track events: (d2, j) order, degree, locality on every pulse;
+    the complete neighbour table (16 columns + overflow) of TWO full events bit for bit against the C oracle
+    (10^8 distances each on the CPU)."""
+    from graphnet_amd import ops
+    from graphnet_amd.synthetic import synthetic_track_batch
+    b = synthetic_track_batch(4, seed=5)
+    assert int(b.n_pulses.min()) >= 4000 and int(b.n_pulses.max()) > 9000
+    k = 16
+    bd = b.to(DEV)
+    ptr32, batch32 = bd.ptr.to(torch.int32), bd.batch.to(torch.int32)
+    t1 = ops.knn_graph(bd.x, [0, 1, 2], batch32, ptr32, k)
+    t2 = ops.knn_graph(bd.x, [0, 1, 2], batch32, ptr32, k)
+    assert torch.equal(t1.nbr, t2.nbr) and torch.equal(t1.ovf, t2.ovf)
+    N = int(bd.x.shape[0])
+    x = bd.x[:, :3].contiguous()
+    nbr = t1.nbr.long()
+    valid = nbr >= 0
+    centre = torch.arange(N, device=DEV)[:, None].expand(N, k)
+    assert bool(valid.all())                                                   # every event has far more than 17 pulses
+    assert bool((nbr != centre).all()) and bool((bd.batch[nbr] == bd.batch[centre]).all())
+    d2 = _d2(x, centre.reshape(-1), nbr.reshape(-1)).reshape(N, k)
+    assert bool((d2[:, 1:] >= d2[:, :-1]).all())
+    tie = d2[:, 1:] == d2[:, :-1]
+    assert bool((nbr[:, 1:][tie] > nbr[:, :-1][tie]).all())
+    # tracks put hundreds of pulses on one DOM: the (k+1)-th "overflow" neighbour exists wherever > k others tie at 0
+    assert int(t1.ovf_cnt.item()) > N // 2
+    b.to("cpu")
+    ptr = b.ptr.numpy()
+    for e in (0, 3):
+        lo, hi = int(ptr[e]), int(ptr[e + 1])
+        sub = oracle.knn_table(b.x[lo:hi], k, torch.tensor([0, hi - lo]), [0, 1, 2], "compat")[0]
+        want = torch.where(sub >= 0, sub + lo, sub).to(torch.int32)
+        assert torch.equal(t1.nbr[lo:hi].cpu(), want[:, :k]), e
+        assert torch.equal(t1.ovf[lo:hi].cpu(), want[:, k]), e
+
+
+def _models(oracle, k):
+    import graphnet_amd as g
+    kw = dict(nb_neighbours=k, global_pooling_schemes=["min", "max", "mean", "sum"])
+    torch.manual_seed(20241016)
+    ref = oracle.StandardModelOracle(7, **kw)
+    m = g.StandardModel(graph_definition=g.KNNGraph(g.IceCube86(), nb_nearest_neighbours=k),
+                        backbone=g.DynEdge(7, **kw),
+                        tasks=[g.EnergyReconstruction(hidden_size=128, loss_function=g.LogCoshLoss(),
+                                                      transform_prediction_and_target=torch.log10)])
+    m.load_state_dict(ref.state_dict())
+    return ref, m.to(DEV)
+
+
+def _track_plus_small(seed=11):
+    """Two events: one >= 4000-pulse track (8-wave k-NN, hubs, S = 16) and one ordinary ~100-pulse event."""
+    import graphnet_amd as g
+    from graphnet_amd.data import Batch, Data
+    from graphnet_amd.synthetic import synthetic_icecube86_batch, synthetic_track_batch
+    big = synthetic_track_batch(1, seed=seed, mean_pulses=4300.0)
+    small = synthetic_icecube86_batch(1, seed=seed + 1)
+    parts = [Data(x=p.x, n_pulses=p.n_pulses[0], energy=p.energy[0]) for p in (big, small)]
+    return Batch.from_data_list(parts)
+
+
+def test_model_k16_teacher_forced_fp32_on_a_track_event(oracle):
+    """fp32 mode, k = 16: outputs within 1e-4, every gradient within 2e-3 of the oracle run on the SAME graphs
+    (teacher forcing), graphs bit-exact the oracle's k-NN of the coordinates they were built from."""
+    b = _track_plus_small()
+    assert int(b.n_pulses.max()) >= 4000 and int(b.n_pulses.shape[0]) == 2      # B < 64: global reverse build
+    ref, m = _models(oracle, 16)
+    m.backbone.set_backend(dtype="fp32")
+    latent, trace = m.backbone(b.to(DEV), return_trace=True)
+    pred = m._tasks[0](latent)
+    loss = m._tasks[0].compute_loss(pred, {"energy": b.energy})
+    loss.backward()
+    torch.cuda.synchronize()
+    bc = b.to("cpu")
+    forced = [t.edge_index().cpu() for t in trace["graphs"]]
+    assert torch.equal(forced[0], oracle.knn_graph(bc.x, 16, bc.batch, [0, 1, 2]))
+    for l in range(1, 4):
+        assert torch.equal(forced[l], oracle.knn_graph(trace["knn_coords"][l - 1].cpu(), 16, bc.batch, slice(0, 3))), l
+    assert max(int(t.rev_nhubs[0]) if t.rev_nhubs is not None else 0 for t in trace["graphs"]) > 0, "no hub list was exercised"
+    lat_o, tr_o = ref.backbone(bc.x, forced[0], bc.batch, bc.n_pulses, return_trace=True, forced_edges=forced)
+    for l in range(5):
+        w = tr_o["conv_out"][l].shape[1]
+        assert rel_err(trace["conv_out"][l][:, :w], tr_o["conv_out"][l]) < 1e-4, l
+    assert rel_err(latent, lat_o) < 1e-4
+    pred_o = oracle.energy_reconstruction(lat_o, ref._affine)
+    loss_o = oracle.log_cosh_loss(pred_o, torch.log10(bc.energy).unsqueeze(1))
+    loss_o.backward()
+    assert rel_err(pred, pred_o) < 1e-4 and abs(float(loss) - float(loss_o)) < 1e-4 * abs(float(loss_o))
+    go = dict(ref.named_parameters())
+    for name, p in m.named_parameters():
+        assert rel_err(p.grad, go[name].grad) < 2e-3, name
+
+
+def test_model_k16_bf16_full_size_finite_deterministic_independent():
+    """bf16 mode at the full configs[4] size (B = 4, ~4 x 10^4 pulses, 6.5 x 10^5 edges per layer): finite loss and
+    gradients, two runs bit-identical, and an event's latent vector does not depend on its batch neighbours."""
+    import graphnet_amd as g
+    from graphnet_amd.data import select_events
+    from graphnet_amd.synthetic import synthetic_track_batch
+    b = synthetic_track_batch(4, seed=5)
+
+    def run(batch):
+        torch.manual_seed(3)
+        m = g.StandardModel(graph_definition=g.KNNGraph(g.IceCube86(), nb_nearest_neighbours=16),
+                            backbone=g.DynEdge(7, nb_neighbours=16, global_pooling_schemes=["min", "max", "mean", "sum"]),
+                            tasks=[g.EnergyReconstruction(hidden_size=128, loss_function=g.LogCoshLoss(),
+                                                          transform_prediction_and_target=torch.log10)]).to(DEV)
+        m.backbone.set_backend(dtype="bf16")
+        latent = m.backbone(batch.to(DEV))
+        loss = m._tasks[0].compute_loss(m._tasks[0](latent), {"energy": batch.energy})
+        loss.backward()
+        torch.cuda.synchronize()
+        return latent.detach().clone(), float(loss), [p.grad.detach().clone() for p in m.parameters()]
+
+    lat1, loss1, g1 = run(b)
+    lat2, loss2, g2 = run(b)
+    b.to("cpu")
+    assert np.isfinite(loss1) and all(bool(torch.isfinite(t).all()) for t in g1) and bool(torch.isfinite(lat1).all())
+    assert loss1 == loss2 and torch.equal(lat1, lat2) and all(torch.equal(a, c) for a, c in zip(g1, g2))
+    sub = select_events(b, [1, 2])
+    lat_sub, _, _ = run(sub)
+    assert torch.equal(lat_sub, lat1[1:3]), "an event's output changed with its batch neighbours"

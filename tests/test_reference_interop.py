@@ -1,0 +1,130 @@
+"""Reference-side interop: ``graphnet.models.StandardModel`` asserts ``isinstance(backbone, Model)``
+(``models/standard_model.py:64``) and its metaclass captures constructor arguments, replacing nested ``Model`` instances
+by their ``.config`` (``utilities/config/model_config.py:317-346``).  The real package cannot be imported in this image
+(no pytorch-lightning / torch-geometric), so a STUB ``graphnet`` with the same class relations - a ``Model`` base built
+by a capturing metaclass that is also an ``ABCMeta``, ``graphnet.models.gnn.gnn.GNN(Model)`` with the reference's
+constructor, and a ``StandardModel`` with the reference's two asserts - is put on ``PYTHONPATH`` of a fresh interpreter.
+No reference file is involved."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+STUB = {
+    "graphnet/__init__.py": "",
+    "graphnet/models/__init__.py": """
+        import inspect
+        from abc import ABC, ABCMeta
+        import torch
+
+        class ModelConfig:
+            def __init__(self, class_name, arguments):
+                self.class_name, self.arguments = class_name, arguments
+
+        class ModelConfigSaverMeta(type):
+            def __call__(cls, *args, **kwargs):
+                created = super().__call__(*args, **kwargs)
+                bound = inspect.signature(created.__init__).bind(*args, **kwargs)
+                bound.apply_defaults()
+                cfg = {k: (v.config if isinstance(v, Model) else v) for k, v in bound.arguments.items()}
+                created._config = ModelConfig(cls.__name__, cfg)
+                return created
+
+        class ModelConfigSaverABC(ModelConfigSaverMeta, ABCMeta):
+            pass
+
+        class Model(torch.nn.Module, ABC, metaclass=ModelConfigSaverABC):
+            @property
+            def config(self):
+                return self._config
+
+        class StandardModel(Model):
+            def __init__(self, *, graph_definition, backbone, tasks=None):
+                super().__init__()
+                assert isinstance(backbone, Model)          # models/standard_model.py:64
+                self.backbone = backbone
+
+            def forward(self, data):
+                return self.backbone(data)
+        """,
+    "graphnet/models/gnn/__init__.py": "from .gnn import GNN",
+    "graphnet/models/gnn/gnn.py": """
+        from abc import abstractmethod
+        from graphnet.models import Model
+
+        class GNN(Model):
+            def __init__(self, nb_inputs, nb_outputs):
+                super().__init__()
+                self._nb_inputs = nb_inputs
+                self._nb_outputs = nb_outputs
+
+            @property
+            def nb_inputs(self):
+                return self._nb_inputs
+
+            @property
+            def nb_outputs(self):
+                return self._nb_outputs
+
+            @abstractmethod
+            def forward(self, data):
+                ...
+        """,
+}
+
+SCRIPT = """
+    import torch, graphnet.models as ref
+    from graphnet.models.gnn.gnn import GNN as RefGNN
+    import graphnet_amd as g
+    from graphnet_amd.model import REFERENCE
+    assert REFERENCE is not None and REFERENCE["Model"] is ref.Model
+    assert issubclass(g.Model, ref.Model) and issubclass(g.GNN, RefGNN) and issubclass(g.DynEdge, ref.Model)
+    backbone = g.DynEdge(7, global_pooling_schemes=["min", "max"], nb_neighbours=6)
+    assert isinstance(backbone, ref.Model) and isinstance(backbone, RefGNN)
+    assert backbone.nb_inputs == 7 and backbone.nb_outputs == 128
+    # the reference's metaclass captured the call (its own ModelConfig type), ours sits beside it
+    assert type(backbone.config) is ref.ModelConfig and backbone.config.class_name == "DynEdge"
+    assert backbone.config.arguments["nb_neighbours"] == 6 and backbone.config.arguments["nb_inputs"] == 7
+    assert backbone.amd_config.arguments["global_pooling_schemes"] == ["min", "max"]
+    # their StandardModel takes our backbone (the isinstance assert) and nests its config
+    m = ref.StandardModel(graph_definition=None, backbone=backbone)
+    assert m.config.arguments["backbone"] is backbone.config
+    # same parameter layout as stand-alone (Appendix B: 1,382,192 backbone parameters for F=7 with 4 pools)
+    full = g.DynEdge(7, global_pooling_schemes=["min", "max", "mean", "sum"])
+    assert sum(p.numel() for p in full.parameters()) == 1382192
+    # our own config round trip still works under the reference's base class
+    again = g.Model.from_config(full.amd_config)
+    assert [k for k, _ in again.named_parameters()] == [k for k, _ in full.named_parameters()]
+    # other Model subclasses of this package construct under the foreign base as well
+    sm = g.StandardModel(graph_definition=g.KNNGraph(g.IceCube86()), backbone=full,
+                         tasks=[g.EnergyReconstruction(hidden_size=128, loss_function=g.LogCoshLoss())])
+    assert isinstance(sm, ref.Model) and "backbone._conv_layers.0.nn.0.weight" in sm.state_dict()
+    print("interop ok")
+"""
+
+
+def test_backbone_is_a_reference_model_when_graphnet_is_importable(tmp_path):
+    for rel, text in STUB.items():
+        path = tmp_path / rel
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_text(textwrap.dedent(text))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), ROOT]))
+    env.pop("GRAPHNET_AMD_NO_REFERENCE", None)
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(SCRIPT)], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0 and "interop ok" in r.stdout, r.stderr[-3000:]
+
+
+def test_stand_alone_tree_without_the_reference():
+    import graphnet_amd as g
+    from graphnet_amd.model import REFERENCE
+    assert REFERENCE is None                                  # this image: graphnet is not importable
+    m = g.DynEdge(7)
+    assert m.config is m.amd_config and isinstance(m, torch_module())
+
+
+def torch_module():
+    import torch
+    return torch.nn.Module
