@@ -1094,10 +1094,10 @@ hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, int H
     const bool s8 = edge_slots(g.K) == 8;
     if (ws_enabled(0) && (long long)g.N * (ldo > H2 ? ldo : H2) < (1LL << 31) && g.N < (1 << 24) &&
         (long long)g.N * 4 * H1p < (1LL << 32)) {                                    // 32-bit offsets, 24-bit node ids
-        if (H1p == 128) { if (s8) GN_FWD_LAUNCH_WS(8, 8, 8); else GN_FWD_LAUNCH_WS(8, 8, 16); }
-        else if (H1 <= 336) { if (s8) GN_FWD_LAUNCH_WS(22, 21, 8); else GN_FWD_LAUNCH_WS(22, 21, 16); }
-        else { if (s8) GN_FWD_LAUNCH_WS(22, 22, 8); else GN_FWD_LAUNCH_WS(22, 22, 16); }
-        return hipGetLastError();
+        // hidden widths 337..352 (all 22 k-steps real) would need 4 more registers for the stationary W2 slice than
+        // 3 waves per SIMD leave (the variant spilled 24 bytes): those shapes take the all-waves-gather kernel below
+        if (H1p == 128) { if (s8) GN_FWD_LAUNCH_WS(8, 8, 8); else GN_FWD_LAUNCH_WS(8, 8, 16); return hipGetLastError(); }
+        if (H1 <= 336) { if (s8) GN_FWD_LAUNCH_WS(22, 21, 8); else GN_FWD_LAUNCH_WS(22, 21, 16); return hipGetLastError(); }
     }
     if (H1p == 128) { if (s8) GN_FWD_LAUNCH(8, 8); else GN_FWD_LAUNCH(8, 16); }
     else { if (s8) GN_FWD_LAUNCH(22, 8); else GN_FWD_LAUNCH(22, 16); }

@@ -312,29 +312,36 @@ __device__ __forceinline__ void tn2_read(Tn2Frags& f, const unsigned char* pa, c
         f.b1[nb] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + nb * 64 + 4 * XP));
     }
 }
-template <bool ONES>
+// PIPE: the transposed fragments of k-step s+1 are requested before the MFMAs of k-step s (two fragment sets).  The
+// variants with fp32 dY hold twice the staging registers and run with ONE set (PIPE = false): with two they spill
+// (20-68 bytes of scratch), and no kernel of this library may use scratch (hipGraph replay).
+template <bool ONES, bool PIPE>
 __device__ __forceinline__ void tn2_tile(const unsigned char* ya, const unsigned char* xb, f32x16 (&acc)[4], f32x16& accb) {
     constexpr int YP = tr_pitch_g(256 * 2), XP = tr_pitch_g(128 * 2);
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-    Tn2Frags f[2];
+    Tn2Frags f[PIPE ? 2 : 1];
     tn2_read(f[0], ya, xb, YP, XP);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        if (s + 1 < 4) tn2_read(f[(s + 1) & 1], ya + 16 * (s + 1) * YP, xb + 16 * (s + 1) * XP, YP, XP);
-        const Tn2Frags& c = f[s & 1];
+        if (PIPE && s + 1 < 4) tn2_read(f[(s + 1) & 1], ya + 16 * (s + 1) * YP, xb + 16 * (s + 1) * XP, YP, XP);
+        const Tn2Frags& c = f[PIPE ? (s & 1) : 0];
         const bf16x8 af = __builtin_bit_cast(bf16x8, (s16x8_t_)__builtin_shufflevector(c.a0, c.a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        s16x8_t_ bv[4];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const s16x8_t_ bv = __builtin_shufflevector(c.b0[nb], c.b1[nb], 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[nb], 0, 0, 0);
-        }
+        for (int nb = 0; nb < 4; ++nb) bv[nb] = __builtin_shufflevector(c.b0[nb], c.b1[nb], 0, 1, 2, 3, 4, 5, 6, 7);
+        if (!PIPE && s + 1 < 4) tn2_read(f[0], ya + 16 * (s + 1) * YP, xb + 16 * (s + 1) * XP, YP, XP);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv[nb]), acc[nb], 0, 0, 0);
         if constexpr (ONES) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);            // keep the next step's reads ahead of this step's MFMAs
     }
 }
-template <typename DYT, typename XT>
+// BIAS: the bias gradient rides along as a ones block (16 more accumulator registers).  Off for the variants with
+// fp32 dY, whose staging registers are twice as many (with it they spilled): their bias gradient is a colsum pass.
+template <typename DYT, typename XT, bool BIAS = sizeof(DYT) == 2>
 __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
     const DYT* __restrict__ dY, long long lddy, int N1, Segs x, int M, int nparts,
     float* __restrict__ slab, float* __restrict__ db_part, int Ktot, int n1_tiles, int k_tiles, int xcd_group)
@@ -406,37 +413,56 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
     for (int j = 0; j < 2; ++j) xok[j] = kcol0 + (sc + 8 * j) * 8 < xw;
     const DYT* ybase = dY + (long long)srow * lddy + n1_0 + sc * 8;
     const XT* xbase = xp + (long long)srow * ldx + kcol0 + sc * 8;
-#define GN_TN2_LOAD(t_, yr, xr)                                                                      \
+#define GN_TN2_LOAD_Y(t_, yr)                                                                        \
     {                                                                                                \
         if ((t_) < tile_end && ((t_) + 1) * TN2_ROWS <= M) {                 /* workgroup-uniform */  \
             const DYT* yp__ = ybase + (long long)(t_) * TN2_ROWS * lddy;                             \
-            const XT* xp__ = xbase + (long long)(t_) * TN2_ROWS * ldx;                               \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) if (yok[j]) load_chunk8_raw(yr[j], yp__ + j * 64); \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) if (xok[j]) load_chunk8_raw(xr[j], xp__ + j * 64); \
         } else {                                                                                     \
             const int m__ = (t_) * TN2_ROWS + srow;                                                  \
             const bool mok__ = (t_) < tile_end && m__ < M;                                           \
             const long long ms__ = mok__ ? m__ : 0;                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
                 load_chunk8(yr[j], dY + ms__ * lddy, n1_0 + (sc + 8 * j) * 8, N1, mok__);            \
+        }                                                                                            \
+    }
+#define GN_TN2_LOAD_X(t_, xr)                                                                        \
+    {                                                                                                \
+        if ((t_) < tile_end && ((t_) + 1) * TN2_ROWS <= M) {                                         \
+            const XT* xp__ = xbase + (long long)(t_) * TN2_ROWS * ldx;                               \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) if (xok[j]) load_chunk8_raw(xr[j], xp__ + j * 64); \
+        } else {                                                                                     \
+            const int m__ = (t_) * TN2_ROWS + srow;                                                  \
+            const bool mok__ = (t_) < tile_end && m__ < M;                                           \
+            const long long ms__ = mok__ ? m__ : 0;                                                  \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                            \
                 load_chunk8(xr[j], xp + ms__ * ldx, kcol0 + (sc + 8 * j) * 8, xw, mok__);            \
         }                                                                                            \
     }
-#define GN_TN2_WRITE(buf_, yr, xr)                                                                   \
+#define GN_TN2_LOAD(t_, yr, xr) { GN_TN2_LOAD_Y(t_, yr); GN_TN2_LOAD_X(t_, xr); }
+#define GN_TN2_WRITE_Y(buf_, yr)                                                                     \
     {                                                                                                \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
             *reinterpret_cast<u32x4*>(&Ys[buf_][srow * YP + (sc + 8 * j) * 16]) = pack_chunk8(yr[j]); \
+    }
+#define GN_TN2_WRITE_X(buf_, xr)                                                                     \
+    {                                                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
             *reinterpret_cast<u32x4*>(&Xs[buf_][srow * XP + (sc + 8 * j) * 16]) = pack_chunk8(xr[j]); \
     }
+#define GN_TN2_WRITE(buf_, yr, xr) { GN_TN2_WRITE_Y(buf_, yr); GN_TN2_WRITE_X(buf_, xr); }
     // out-of-range float4s are read from a clamped (valid) address and zeroed: branch-free staging
 
     // fp32 operands take twice the staging registers: one set (rows requested one tile ahead) for those
     constexpr bool DEEP = sizeof(DYT) == 2 && sizeof(XT) == 2;
     GN_TN2_LOAD(tile, yr0, xr0);
     GN_TN2_WRITE(0, yr0, xr0);
-    GN_TN2_LOAD(tile + 1, yr0, xr0);
+    // both operands fp32: even one set of staging registers for dY AND X beside the accumulators does not fit
+    // (28 bytes of scratch) - X of the next tile is then requested AFTER the tile's MFMAs (its latency is exposed;
+    // this variant serves the unfused GELU / LayerNorm / BatchNorm paths only)
+    constexpr bool LATE_X = sizeof(DYT) == 4 && sizeof(XT) == 4;
+    if constexpr (LATE_X) { GN_TN2_LOAD_Y(tile + 1, yr0); }
+    else { GN_TN2_LOAD(tile + 1, yr0, xr0); }
     if constexpr (DEEP) GN_TN2_LOAD(tile + 2, yr1, xr1);
     __syncthreads();
 
@@ -446,8 +472,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
     const int xb_off = tr_row * XP + tr_col;
 
     // one 64-row tile: the transposed fragments of k-step s+1 are requested before the MFMAs of k-step s
-#define GN_TN2_MMA(buf_) { if (first_k) tn2_tile<true>(&Ys[buf_][ya_off], &Xs[buf_][xb_off], acc, accb); \
-                           else tn2_tile<false>(&Ys[buf_][ya_off], &Xs[buf_][xb_off], acc, accb); }
+#define GN_TN2_MMA(buf_) { if (BIAS && first_k) tn2_tile<BIAS, sizeof(DYT) == 2>(&Ys[buf_][ya_off], &Xs[buf_][xb_off], acc, accb); \
+                           else tn2_tile<false, sizeof(DYT) == 2>(&Ys[buf_][ya_off], &Xs[buf_][xb_off], acc, accb); }
     if constexpr (DEEP) {
         // two tiles per trip: set 0 holds tile+1 / tile+3, set 1 holds tile+2 / tile+4
         for (; tile < tile_end; tile += 2) {
@@ -463,14 +489,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
     } else {
         int buf = 0;
         for (; tile < tile_end; ++tile, buf ^= 1) {
-            if (buf == 0) { GN_TN2_MMA(0); GN_TN2_WRITE(1, yr0, xr0); }
-            else { GN_TN2_MMA(1); GN_TN2_WRITE(0, yr0, xr0); }
-            GN_TN2_LOAD(tile + 2, yr0, xr0);
+            if constexpr (LATE_X) {
+                if (buf == 0) { GN_TN2_MMA(0); } else { GN_TN2_MMA(1); }
+                GN_TN2_LOAD_X(tile + 1, xr0);
+                if (buf == 0) { GN_TN2_WRITE(1, yr0, xr0); } else { GN_TN2_WRITE(0, yr0, xr0); }
+                GN_TN2_LOAD_Y(tile + 2, yr0);
+            } else {
+                if (buf == 0) { GN_TN2_MMA(0); GN_TN2_WRITE(1, yr0, xr0); }
+                else { GN_TN2_MMA(1); GN_TN2_WRITE(0, yr0, xr0); }
+                GN_TN2_LOAD(tile + 2, yr0, xr0);
+            }
             __syncthreads();
         }
     }
 #undef GN_TN2_LOAD
+#undef GN_TN2_LOAD_Y
+#undef GN_TN2_LOAD_X
 #undef GN_TN2_WRITE
+#undef GN_TN2_WRITE_Y
+#undef GN_TN2_WRITE_X
 #undef GN_TN2_MMA
 
     float* out = slab + (long long)part * N1 * Ktot;
@@ -485,7 +522,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
             }
         }
     }
-    if (first_k && db_part && r == 0) {             // every column of the ones block holds colsum(dY)
+    if (BIAS && first_k && db_part && r == 0) {     // every column of the ones block holds colsum(dY)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int n1 = n1_0 + wave * 32 + acc_row(q, h);
@@ -689,7 +726,7 @@ hipError_t launch_gemm_tn(int mode, const void* dY, int dy_lowp, long long lddy,
         const int pops2 = n1t * ktiles2;
         const int grp = gemm_tn_xcd_group(pops2) && parts % 8 == 0 ? 1 : 0;
         const dim3 grid(grp ? 8 * (parts / 8) * pops2 : pops2 * parts), block(512);
-        float* dbp = db ? db_part : nullptr;
+        float* dbp = (db && dy_lowp) ? db_part : nullptr;      // fp32 dY: bias gradient by the colsum pass below
         if (dy_lowp && x_lowp)
             hipLaunchKernelGGL((gemm_tn_v2_kernel<__bf16, __bf16>), grid, block, 0, st, (const __bf16*)dY, lddy, N1, x, M,
                                parts, slab, dbp, Ktot, n1t, ktiles2, grp);
@@ -703,9 +740,15 @@ hipError_t launch_gemm_tn(int mode, const void* dY, int dy_lowp, long long lddy,
             hipLaunchKernelGGL((gemm_tn_v2_kernel<float, float>), grid, block, 0, st, (const float*)dY, lddy, N1, x, M,
                                parts, slab, dbp, Ktot, n1t, ktiles2, grp);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(count, RS_ELEMS)), dim3(256), 0, st, slab, parts, count, dW, accum);
-        if (db)
+        if (db && dy_lowp)
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv_(N1, RS_ELEMS)), dim3(256), 0, st, db_part, parts, (long long)N1,
                                db, accum);
+        else if (db)
+            for (int c0 = 0; c0 < N1; c0 += COLSUM_MAXC) {
+                const int cw = N1 - c0 < COLSUM_MAXC ? N1 - c0 : COLSUM_MAXC;
+                hipError_t e = launch_colsum((const float*)dY + c0, lddy, M, cw, db_part, db + c0, accum, st);
+                if (e != hipSuccess) return e;
+            }
         return hipGetLastError();
     }
     const int splits = gemm_tn_splits_for(M, cdiv_(N1, 128) * ktiles);

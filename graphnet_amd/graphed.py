@@ -10,12 +10,14 @@ graph 2: optimizer step), so RCCL is never part of a capture.
 
 Semantics are those of ``StandardModel.fit``'s eager loop (``models/easy_model.py:237-256``).
 
-Status: EXPERIMENTAL, off by default (``bench.py --graph``).  At test scale (24 events) the replay follows
-the eager loop to ~1e-6 in the loss (not bit for bit: the library GEMMs of the tiny read-out pick other
-algorithms under capture).  At bench scale (1024 events) the replays 7..26 of one graph raised "Memory access fault ... write access to a
-read-only page" (the first ten replays never do, with or without host synchronisation, and limiting the
-replays in flight to two does not help), so the cause is still open; nothing in the default path depends on
-this module.
+Status: opt-in (``bench.py --graph``); the replay follows the eager loop to ~1e-5 in the loss (not bit for bit: the
+library GEMMs of the tiny read-out pick other algorithms under capture).  History: in round 1 replays 7..26 of a
+B = 1024 step raised "Memory access fault ... write access to a read-only page".  The one thing that set the faulting
+step apart from every clean one was a kernel with PRIVATE-SEGMENT (scratch) memory in the captured graph:
+``edge_fwd_ws_kernel<22,21,8>`` spilled 48 bytes per lane.  Eager launches of that kernel never faulted; with the
+spill removed (csrc/edgeconv_v2.hip: one select-free hot path) 38 replays of the same step, same size, same seeds run
+clean and reproduce the eager losses.  Rule kept by ``tests/test_cabi_exports.py``: no kernel of the library may have
+a non-zero private segment.
 At least one eager warm-up step is required: the optimizer creates its state on the first ``step()``, and
 state created *inside* the capture would be re-initialised by every replay.
 """

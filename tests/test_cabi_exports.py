@@ -60,3 +60,21 @@ def test_code_object_targets_gfx950_only():
     assert b"gfx950" in data
     for other in (b"gfx942", b"gfx90a", b"sm_90"):
         assert other not in data
+
+
+def test_no_kernel_uses_scratch_memory():
+    """Every kernel of the library must have a private-segment size of 0: a register spill costs a scratch round trip
+    with a full ``vmcnt`` drain in the hot loops, and hipGraph replays of a training step that contained a kernel
+    with scratch (``edge_fwd_ws_kernel<22,21,8>``, 48 bytes) ended in "Memory access fault ... write access to a
+    read-only page" after a handful of replays; with the spill gone the same replays run clean."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("code_object_meta", os.path.join(root, "tools", "code_object_meta.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from graphnet_amd import _lib
+    ks = mod.kernels(_lib.LIB_PATH)
+    assert len(ks) > 100 and all("gfx950" in k["arch"] for k in ks)
+    bad = [(k["name"], k["scratch"]) for k in ks if k["scratch"]]
+    assert not bad, bad
