@@ -346,7 +346,10 @@ def test_linear_wgrad_and_colsum(name, mode, tol):
         a = ops.linear_wgrad(mode, dY16.to(DEV), 336, [(xa16.to(DEV), 32), (xb16.to(DEV), 256)], with_bias=True)
         b_ = ops.linear_wgrad(mode, dY16.float().to(DEV), 336, [(xa16.float().to(DEV), 32), (xb16.float().to(DEV), 256)],
                               with_bias=True)
-        assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1])
+        assert torch.equal(a[0], b_[0])
+        # bias gradient: bf16 dY rides along as a ones block of the MFMA, fp32 dY takes the colsum pass (the ones block
+        # would cost 16 registers the fp32 staging needs) - same values, another summation order
+        assert rel_err(a[1], b_[1]) < 1e-5
         c = ops.linear_wgrad(mode, dY16.to(DEV), 336, [(xa16.float().to(DEV), 32), (xb16.float().to(DEV), 256)])
         assert torch.equal(c, a[0]), "mixed bf16 dY / fp32 X rows"
 
