@@ -26,7 +26,23 @@ struct KnnCols { int c[KNN_DMAX]; };
 // wave only ever scans candidates of ITS OWN event (a tile spanning events would scan their union).
 // tile_ptr[e] = sum_{e'<e} ceil(n_e'/64) is built once per batch by knn_plan_kernel; a workgroup (one
 // wave) finds its event by binary search over tile_ptr (wave-uniform scalar loads).
-constexpr int KNN_BIG = 256;   // events above this many pulses: candidates split over 8 waves per query tile
+constexpr int KNN_BIG = 256;   // events above this many pulses: candidates split over 8 waves per query tile ...
+// ... unless the batch holds so many such tiles that one wave per tile already fills the chip (BASELINE configs[4]:
+// 16 events x 10^4 pulses = 2670 tiles on 1024 SIMDs).  A wave that scans its WHOLE event rejects most candidates
+// against its running k-th distance with one wave-uniform branch (at 10^4 candidates ~35 % of them still trigger the
+// sorted insert for some lane of the wave); a wave that scans one eighth of the event never gets a tight bound
+// (nearly every candidate triggers it) and the eight lists must be merged: 2.2x the instructions.  The split only
+// pays as a LATENCY measure for a few big events among many small ones.  The choice is made on the device from the
+// plan (no host read-back): tile_ptr[B + 1] = number of tiles of big events.
+constexpr int KNN_SPLIT_MAX_TILES = 768;
+// Candidates that beat a lane's running k-th distance are not inserted at once: the sorted insert is ~4 KMAX vector
+// instructions that the WHOLE wave executes even when one lane needs it, and with 64 different queries per wave some
+// lane needs it for most candidates (every candidate of a 150-pulse event, ~35 % of them at 10^4 pulses).  Each lane
+// appends its (d2, j) to a private FIFO in LDS instead (2 LDS writes); the wave runs the insert sequence once per
+// FIFO slot when some lane's FIFO is nearly full: ~ max-over-lanes(inserts) sequences per tile instead of one per
+// candidate.  Order is kept (a FIFO per lane, candidates arrive in ascending index), the stale k-th distance only
+// admits a few candidates that the real insert then rejects: the lists are the same, entry for entry.
+constexpr int KNN_QD = 8;      // FIFO entries per lane; flushed when a lane has more than KNN_QD - 4 (a group adds <= 4)
 __global__ __launch_bounds__(256) void knn_plan_kernel(const int* __restrict__ ptr, int B, int* __restrict__ tile_ptr) {
     __shared__ int lds[256 / 64];
     int carry = 0;
@@ -71,7 +87,7 @@ __global__ __launch_bounds__(256) void knn_plan_kernel(const int* __restrict__ p
 // 5000-pulse event in a batch is a 0.5 ms tail on a 0.13 ms kernel.
 template <int KMAX, int DT, int CW>
 __device__ __forceinline__ void knn_tile(
-    const int w, unsigned char* lds_raw, const float* __restrict__ x, long long ldx, const KnnCols& cols, int Drt,
+    const int w, unsigned char* lds_raw, unsigned char* lds_queue, const float* __restrict__ x, long long ldx, const KnnCols& cols, int Drt,
     const int* __restrict__ ptr, const int* __restrict__ tile_ptr, int B, int N, int k, int strict,
     int* __restrict__ nbr, int* __restrict__ ovf)
 {
@@ -85,17 +101,21 @@ __device__ __forceinline__ void knn_tile(
     }
     const int ev = elo;
     const int hi = min(ptr[ev + 1], N), lo = min(max(ptr[ev], 0), hi);   // never index past x[N]
-    if ((CW == 1) != (hi - lo <= KNN_BIG)) return;   // the other launch owns this event (workgroup-uniform)
-    const int kk = strict ? k : k + 1;
+    const bool split_big = tile_ptr[B + 1] < KNN_SPLIT_MAX_TILES;         // batch-uniform (see KNN_SPLIT_MAX_TILES)
+    if ((CW == 1) != (!split_big || hi - lo <= KNN_BIG)) return;   // the other launch owns this event (workgroup-uniform)
+    const int kk = k + 1;
     const int lane = (int)threadIdx.x & (KNN_TILE - 1), wv = (int)threadIdx.x / KNN_TILE;
     const int q = lo + (w - tile_ptr[ev]) * KNN_TILE + lane;
     const bool active = q < hi;
-    const float INF = __builtin_inff();
     float (*cand)[KNN_CH] = reinterpret_cast<float (*)[KNN_CH]>(lds_raw + wv * DM * KNN_CH * 4);   // this wave's staging
+    float* qd = reinterpret_cast<float*>(lds_queue) + wv * (2 * KNN_QD * KNN_TILE);               // this wave's FIFOs
+    int* qj = reinterpret_cast<int*>(qd + KNN_QD * KNN_TILE);
+    int qn = 0;                                                                                   // entries of this lane
 
+    // lanes without a query carry NaN coordinates: every distance is NaN, no comparison holds, nothing is queued
     float qc[DM];
 #pragma unroll
-    for (int d = 0; d < DM; ++d) qc[d] = (active && d < D) ? x[(long long)q * ldx + cols.c[d]] : 0.0f;
+    for (int d = 0; d < DM; ++d) qc[d] = d < D ? (active ? x[(long long)q * ldx + cols.c[d]] : __builtin_nanf("")) : 0.0f;
     float bd[KMAX];
     int bj[KMAX];
 #pragma unroll
@@ -113,6 +133,18 @@ __device__ __forceinline__ void knn_tile(
         }                                                                                             \
         bj[0] = ct ? (j_) : bj[0];                                                                    \
         bd[0] = ct ? (d2_) : bd[0];                                                                   \
+    }
+
+#define GN_KNN_FLUSH()                                                                                \
+    {                                                                                                 \
+        for (int s__ = 0; __ballot(s__ < qn) != 0ull; ++s__) {                                        \
+            if (s__ < qn) {                                                                           \
+                const float dq__ = qd[s__ * KNN_TILE + lane];                                         \
+                const int jq__ = qj[s__ * KNN_TILE + lane];                                           \
+                GN_KNN_INSERT(dq__, jq__);                                                            \
+            }                                                                                         \
+        }                                                                                             \
+        qn = 0;                                                                                       \
     }
 
     // this wave's piece of the candidate range (multiple of 4 long except the last)
@@ -140,9 +172,9 @@ __device__ __forceinline__ void knn_tile(
                     cd[d][0] = v[0]; cd[d][1] = v[1]; cd[d][2] = v[2]; cd[d][3] = v[3];
                 }
             }
+            float d2v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int j = c0 + jl + u;
                 float d2 = 0.0f;
 #pragma unroll
                 for (int d = 0; d < DM; ++d) {
@@ -152,13 +184,31 @@ __device__ __forceinline__ void knn_tile(
                         d2 = d2 + sq;                    // 0 + sq first: same left-to-right sum as the oracle
                     }
                 }
-                // inactive lanes, the query itself (strict) and NaN/inf distances never enter the list
-                const bool ok = active && !(strict && j == q) && d2 < INF;
-                d2 = ok ? d2 : INF;
-                GN_KNN_INSERT(d2, j);
+                // NaN / inf distances (and the NaN of lanes without a query) fail every "<" below.  The query itself is
+                // scanned like any other candidate in BOTH modes: strict mode (self excluded, degree <= k) is the
+                // k+1-with-self list with the query dropped and cut to k entries - the same k entries, because the
+                // query can only be missing from that list when k+1 earlier pulses tie with it at distance 0
+                d2v[u] = d2;
+            }
+            // wave-uniform rejection of the whole group of four against the running k-th distances: in a long scan
+            // (thousands of candidates) most groups beat no lane's list.  fmin ignores NaN operands; four NaNs (a lane
+            // without a query) compare false.
+            const float thr = bd[KMAX - 1];
+            const float dmin = __builtin_fminf(__builtin_fminf(d2v[0], d2v[1]), __builtin_fminf(d2v[2], d2v[3]));
+            if (__ballot(dmin < thr) != 0ull) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (d2v[u] < thr) {
+                        qd[qn * KNN_TILE + lane] = d2v[u];
+                        qj[qn * KNN_TILE + lane] = c0 + jl + u;
+                        ++qn;
+                    }
+                }
+                if (__ballot(qn > KNN_QD - 4) != 0ull) GN_KNN_FLUSH();
             }
         }
     }
+    GN_KNN_FLUSH();
     if constexpr (CW > 1) {
         // merge: waves 1.. publish their lists, wave 0 inserts them in ascending piece (= index) order
         __syncthreads();                                    // everybody is done with the staging area
@@ -182,6 +232,7 @@ __device__ __forceinline__ void knn_tile(
             }
     }
 #undef GN_KNN_INSERT
+#undef GN_KNN_FLUSH
     if (active && wv == 0) {
         int c = 0;
         int extra = -1;
@@ -191,7 +242,7 @@ __device__ __forceinline__ void knn_tile(
                 const int j = bj[e];
                 if (j >= 0 && j != q) {
                     if (c < k) nbr[(long long)q * k + c] = j;
-                    else extra = j;
+                    else if (!strict) extra = j;
                     ++c;
                 }
             }
@@ -211,14 +262,17 @@ __global__ __launch_bounds__(KNN_TILE * CW) void knn_kernel(
     constexpr int CAND_BYTES = CW * DM * KNN_CH * 4;
     constexpr int LIST_BYTES = (CW - 1) * KMAX * KNN_TILE * 8;
     constexpr int LDS_BYTES = CAND_BYTES > LIST_BYTES ? CAND_BYTES : LIST_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    constexpr int QUEUE_BYTES = CW * 2 * KNN_QD * KNN_TILE * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[LDS_BYTES + QUEUE_BYTES];
+    unsigned char* lds_raw = lds_all;
+    unsigned char* lds_queue = lds_all + LDS_BYTES;
     if constexpr (CW == 1) {
         if ((int)blockIdx.x < tile_ptr[B])
-            knn_tile<KMAX, DT, CW>((int)blockIdx.x, lds_raw, x, ldx, cols, Drt, ptr, tile_ptr, B, N, k, strict, nbr, ovf);
+            knn_tile<KMAX, DT, CW>((int)blockIdx.x, lds_raw, lds_queue, x, ldx, cols, Drt, ptr, tile_ptr, B, N, k, strict, nbr, ovf);
     } else {
-        const int nbig = tile_ptr[B + 1];                   // usually 0: the workgroups leave at once
+        const int nbig = tile_ptr[B + 1] < KNN_SPLIT_MAX_TILES ? tile_ptr[B + 1] : 0;   // usually 0: the workgroups leave at once
         for (int i = blockIdx.x; i < nbig; i += gridDim.x) {
-            knn_tile<KMAX, DT, CW>(tile_ptr[B + 2 + i], lds_raw, x, ldx, cols, Drt, ptr, tile_ptr, B, N, k, strict, nbr, ovf);
+            knn_tile<KMAX, DT, CW>(tile_ptr[B + 2 + i], lds_raw, lds_queue, x, ldx, cols, Drt, ptr, tile_ptr, B, N, k, strict, nbr, ovf);
             __syncthreads();                                 // LDS reuse by the next tile
         }
     }
@@ -579,7 +633,7 @@ hipError_t launch_knn(const float* x, long long ldx, const int* cols, int D, con
     if (N == 0 || B == 0) return hipSuccess;
     KnnCols kc;
     for (int d = 0; d < KNN_DMAX; ++d) kc.c[d] = d < D ? cols[d] : 0;
-    const int kk = strict ? k : k + 1;
+    const int kk = k + 1;                                   // list length in both modes (strict drops the query at the end)
     // upper bound of sum ceil(n_e/64) known without reading ptr on the host; surplus workgroups exit at once
     const long long tiles = (long long)N / KNN_TILE + B;
     dim3 grid((unsigned)tiles), block(KNN_TILE);
