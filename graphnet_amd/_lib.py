@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphnet_amd.so")
 _lib = None
-ABI_VERSION = 2          # GN_ABI_VERSION of include/graphnet_amd.h these signatures mirror
+ABI_VERSION = 3          # GN_ABI_VERSION of include/graphnet_amd.h these signatures mirror
 
 P = c_void_p
 I32 = c_int32
@@ -51,6 +51,11 @@ SIGNATURES = {
     "gn_edgeconv_dw2_slabs": (I32, [I32, I32, I32, I32, I32]),
     "gn_edgeconv_dw2": (I32, [I32, P, P, P, P, I32, I32, P, I32, I32, I32, P, I64, P, P, P, P]),
     "gn_edgeconv_dq_gather": (I32, [I32, P, I32, P, P, P, P, I32, P, I64, P]),
+    "gn_edgeconv_max_supported": (I32, [I32, I32, I32, I32]),
+    "gn_edgeconv_max_dw2_slabs": (I32, [I32, I32, I32]),
+    "gn_edgeconv_max_fwd": (I32, [P, I32, I32, P, I32, P, P, I32, P, I64, P, P]),
+    "gn_edgeconv_max_dw2": (I32, [P, I32, I32, P, I32, I32, I32, P, I64, P, P, P, P]),
+    "gn_edgeconv_max_bwd": (I32, [P, I32, I32, I32, I32, P, I64, P, P, I32, P, P, I64, P]),
     "gn_edge_rows": (I32, [P, P, P, P, I32, I32, P, P, P]),
     "gn_edge_gather_pre": (I32, [P, I32, P, P, I64, I32, P, I32, P]),
     "gn_rownorm_act_fwd": (I32, [P, I64, I32, P, P, P, c_float, I32, P, I64, I32, P, I64, P, I64, P]),

@@ -190,6 +190,41 @@ int gn_edgeconv_bwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre,
     return fail(gn::launch_edge_bwd(mode, make_graph(nbr, ovf_centre, ovf_src, ovf_cnt, N, K), PQ, H1p, H2, gout, ldg,
                                     saved, W2Tp, H2p, dpre, dP, ldp, S(stream)), "gn_edgeconv_bwd");
 }
+// ---- EdgeConvTito (leaky relu edge MLP, max aggregation): fused bf16 kernels
+int32_t gn_edgeconv_max_supported(int32_t mode, int32_t K, int32_t H1p, int32_t H2) {
+    return gn::edge_max_supported(mode, K, H1p, H2);
+}
+int32_t gn_edgeconv_max_dw2_slabs(int32_t N, int32_t K, int32_t H1p) { return gn::edge_max_dw2_slabs(N, K, H1p); }
+int gn_edgeconv_max_fwd(const int32_t* nbr, int32_t N, int32_t K, const void* PQ, int32_t H1p, const void* W2p,
+                        const float* b2, int32_t H2, void* out, int64_t ldo, void* saved, void* stream) {
+    if (K < 1 || K > 16 || N < 0 || (reinterpret_cast<uintptr_t>(PQ) & 15) || (reinterpret_cast<uintptr_t>(W2p) & 15) ||
+        (reinterpret_cast<uintptr_t>(saved) & 15))
+        return bad("gn_edgeconv_max_fwd", "need 1<=K<=16 and 16-byte aligned PQ / W2p / saved");
+    hipError_t r = gn::launch_edge_max_fwd(make_graph(nbr, nullptr, nullptr, nullptr, N, K), PQ, H1p, W2p, b2, H2, out, ldo,
+                                           saved, S(stream));
+    if (r == hipErrorNotSupported) return bad("gn_edgeconv_max_fwd", "shape outside the fused envelope (gn_edgeconv_max_supported)");
+    return fail(r, "gn_edgeconv_max_fwd");
+}
+int gn_edgeconv_max_dw2(const int32_t* nbr, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H1, int32_t H2,
+                        const void* gout, int64_t ldg, void* saved, float* slab, float* db2_part, void* stream) {
+    if (K < 1 || K > 16 || N < 1 || H1 > H1p || (ldg & 7) || (reinterpret_cast<uintptr_t>(gout) & 15))
+        return bad("gn_edgeconv_max_dw2", "bad shapes");
+    hipError_t r = gn::launch_edge_max_dw2(make_graph(nbr, nullptr, nullptr, nullptr, N, K), PQ, H1p, H1, H2, gout, ldg, saved,
+                                           slab, db2_part, S(stream));
+    if (r == hipErrorNotSupported) return bad("gn_edgeconv_max_dw2", "shape outside the fused envelope (gn_edgeconv_max_supported)");
+    return fail(r, "gn_edgeconv_max_dw2");
+}
+int gn_edgeconv_max_bwd(const int32_t* nbr, int32_t N, int32_t K, int32_t H1p, int32_t H2, const void* gout, int64_t ldg,
+                        const void* saved, const void* W2Tp, int32_t H2p, void* dpre, void* dP, int64_t ldp, void* stream) {
+    if (K < 1 || K > 16 || N < 0 || (ldg & 7) || (ldp & 7) || (reinterpret_cast<uintptr_t>(gout) & 15) ||
+        (reinterpret_cast<uintptr_t>(dP) & 15))
+        return bad("gn_edgeconv_max_bwd", "need 1<=K<=16, gout / dP 16-byte aligned with 16-byte row pitches");
+    hipError_t r = gn::launch_edge_max_bwd(make_graph(nbr, nullptr, nullptr, nullptr, N, K), H1p, H2, gout, ldg, saved, W2Tp, H2p,
+                                           dpre, dP, ldp, S(stream));
+    if (r == hipErrorNotSupported) return bad("gn_edgeconv_max_bwd", "shape outside the fused envelope (gn_edgeconv_max_supported)");
+    return fail(r, "gn_edgeconv_max_bwd");
+}
+
 int gn_edgeconv_dq_gather(int32_t mode, const void* dpre, int32_t H1p, const int32_t* rev_ptr, const int32_t* rev_rows,
                           const int32_t* hubs, const int32_t* nhubs, int32_t N, void* dQ, int64_t ldq, void* stream) {
     hipError_t r = gn::launch_dq_gather(mode, dpre, H1p, rev_ptr, rev_rows, hubs, nhubs, N, dQ, ldq, S(stream));

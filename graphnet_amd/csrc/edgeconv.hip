@@ -655,7 +655,16 @@ hipError_t launch_edge_bwd_v2(const EdgeGraph& g, int H1p, int H2, const void* g
                               const unsigned char* maskB, const unsigned char* hbits, const void* W2Tp, int H2p,
                               void* dpre, void* dP, long long ldp, int num_cus, hipStream_t st);
 bool edge_v2_shape_ok(int K, int H1p, int H2);
+bool edge_v2_max_shape_ok(int K, int H1p, int H2);
 int edge_dw2_v2_parts(int N, int K, int H1p, int num_cus);
+hipError_t launch_edge_max_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
+                                  void* out, long long ldo, unsigned char* maskB, int num_cus, hipStream_t st);
+hipError_t launch_edge_max_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout,
+                                  long long ldg, const unsigned char* maskB, unsigned char* hbits, float* slab,
+                                  float* db2_part, int num_cus, hipStream_t st);
+hipError_t launch_edge_max_bwd_v2(const EdgeGraph& g, int H1p, int H2, const void* gout, long long ldg,
+                                  const unsigned char* maskB, const unsigned char* hbits, const void* W2Tp, int H2p,
+                                  void* dpre, void* dP, long long ldp, int num_cus, hipStream_t st);
 constexpr int DW2_OVF_SPLITS = 40;    // x 6 column tiles = 240 workgroups: tie-heavy graphs (many pulses per DOM) have ~N overflow rows
 
 int device_cus() {
@@ -796,6 +805,34 @@ hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p
     if (e != hipSuccess) return e;
     return edge_dw2_t<__bf16>(g, PQ, H1p, H1, H2, gout, ldg, words, main_rows, g.N,
                               slab + (long long)parts * H2 * H1, db2_part + (long long)parts * H2, DW2_OVF_SPLITS, st);
+}
+
+// ---- EdgeConvTito (leaky relu edge MLP, max aggregation; models/components/layers.py:72-114): fused kernels for
+// bf16 tables WITHOUT overflow rows, K <= 16, H1p = H2 = 256.  hipErrorNotSupported otherwise: the caller then runs
+// the unfused edge-row path (csrc/generic.hip).  `saved` has the layout of the relu variant (saved_layout()).
+int edge_max_supported(int mode, int K, int H1p, int H2) {
+    return mode == 1 && v2_enabled() && edge_v2_max_shape_ok(K, H1p, H2) ? 1 : 0;
+}
+int edge_max_dw2_slabs(int N, int K, int H1p) { return edge_dw2_v2_parts(N, K, H1p, device_cus()); }
+hipError_t launch_edge_max_fwd(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
+                               void* out, long long ldo, void* saved, hipStream_t st) {
+    const SavedLayout L = saved_layout(g.N, edge_slots(g.K), H1p, H2);
+    return launch_edge_max_fwd_v2(g, PQ, H1p, W2p, b2, H2, out, ldo, reinterpret_cast<unsigned char*>(saved) + L.off_maskB,
+                                  device_cus(), st);
+}
+hipError_t launch_edge_max_dw2(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout, long long ldg,
+                               void* saved, float* slab, float* db2_part, hipStream_t st) {
+    const SavedLayout L = saved_layout(g.N, edge_slots(g.K), H1p, H2);
+    unsigned char* sb = reinterpret_cast<unsigned char*>(saved);
+    return launch_edge_max_dw2_v2(g, PQ, H1p, H1, H2, gout, ldg, sb + L.off_maskB, sb + L.off_hbits, slab, db2_part,
+                                  device_cus(), st);
+}
+hipError_t launch_edge_max_bwd(const EdgeGraph& g, int H1p, int H2, const void* gout, long long ldg, const void* saved,
+                               const void* W2Tp, int H2p, void* dpre, void* dP, long long ldp, hipStream_t st) {
+    const SavedLayout L = saved_layout(g.N, edge_slots(g.K), H1p, H2);
+    const unsigned char* sb = reinterpret_cast<const unsigned char*>(saved);
+    return launch_edge_max_bwd_v2(g, H1p, H2, gout, ldg, sb + L.off_maskB, sb + L.off_hbits, W2Tp, H2p, dpre, dP, ldp,
+                                  device_cus(), st);
 }
 
 // dQ is float in mode 0 and bf16 in mode 1 (like dpre)

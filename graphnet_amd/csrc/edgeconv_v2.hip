@@ -55,6 +55,38 @@ __device__ __forceinline__ u32x4 relu_sum_bf16x8(u32x4 p, u32x4 q) {
     }
     return o;
 }
+// EdgeConvTito variant (models/components/layers.py:72-114: LeakyReLU edge MLP, max aggregation): h = leaky_relu(p + q)
+// = max(x, 0.01 x) in fp32 before the rounding to bf16 (torch's default negative_slope)
+__device__ __forceinline__ u32x4 leaky_sum_bf16x8(u32x4 p, u32x4 q) {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float plo = __builtin_bit_cast(float, p[w] << 16), phi = __builtin_bit_cast(float, p[w] & 0xffff0000u);
+        const float qlo = __builtin_bit_cast(float, q[w] << 16), qhi = __builtin_bit_cast(float, q[w] & 0xffff0000u);
+        const float xl = plo + qlo, xh = phi + qhi;
+        o[w] = pack_bf16x2(fmaxf(xl, 0.01f * xl), fmaxf(xh, 0.01f * xh));
+    }
+    return o;
+}
+// V = 0: relu (DynEdge), V = 1: leaky relu (EdgeConvTito)
+template <int V> __device__ __forceinline__ u32x4 act_sum_bf16x8(u32x4 p, u32x4 q) {
+    if constexpr (V == 0) return relu_sum_bf16x8(p, q);
+    else return leaky_sum_bf16x8(p, q);
+}
+// 8 "h > 0" flags of a packed bf16x8 that may hold NEGATIVE values (leaky relu): as signed 16-bit integers a bf16 is
+// > 0 exactly when its integer is > 0 (sign-magnitude, -0.0 = 0x8000 < 0): clamp to [0, 1], then as below
+__device__ __forceinline__ unsigned int positive_bits_bf16x8(u32x4 o) {
+    unsigned int t = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned int ow = o[w];                    // copy the element first: bit_cast of a vector-element lvalue reads element 0
+        const s16x2 c = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(s16x2, ow), (s16x2){0, 0}),
+                                                  (s16x2){1, 1});
+        const unsigned int k = (1u << (2 * w)) | (2u << (2 * w + 16));
+        t = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, c), __builtin_bit_cast(u16x2, k), t, false);
+    }
+    return t;
+}
 // 8 "h > 0" flags of a packed NON-NEGATIVE bf16x8 (bit c = column c of the chunk): min(half, 1) is the flag of a
 // half in [0, 0x7fff]; a 16-bit dot product with the weights (2^2w, 2^(2w+1)) drops both flags of a dword into place:
 // two instructions per dword.
@@ -423,7 +455,71 @@ __device__ __forceinline__ void fwd_phase(const unsigned char* a, const bf16x8 (
 constexpr int WS_THREADS = 768;
 // KSTEPS = H1p / 16 (row layout of P|Q and W2p), KUSE = ceil(H1 / 16) <= KSTEPS: the k-steps that hold real columns
 // (H1 = 336: 21 of 22: the last one is the packed layout's zero padding and is neither gathered nor multiplied).
-template <int KSTEPS, int KUSE, int S>
+// ---- EdgeConvTito epilogue of one 32-row block: max over a centre's valid slots of (acc + b2), the slot that
+// supplied it (first maximum in slot order, as csrc/generic.hip: slot_reduce_kernel), then leaky relu of the maximum (a
+// strictly increasing activation commutes with max).  Returns this lane's centres (S = 8: 2h, 2h+1; S = 16: h):
+// value (0 when the centre has no edge in these slots) and the ONE-HOT slot mask (0 = none) - the backward kernels
+// read it exactly like the relu slot masks: d(out)/d(row) is non-zero on the arg row only.
+template <int S>
+__device__ __forceinline__ void max_epi_block(const f32x16& acc, float bias, unsigned int vrow, int h, float (&sval)[2],
+                                              unsigned int& smsk) {
+    float gm[4];
+    int ga[4];                                         // per register group c: max / slot (within the group) / -1
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float m = -3.0e38f;
+        int a = -1;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int q = 4 * c + qq;
+            const bool ok = (vrow >> acc_row(q, 0)) & 1u;
+            const float v = acc[q] + bias;
+            if (ok && v > m) { m = v; a = qq; }
+        }
+        gm[c] = m; ga[c] = a;
+    }
+    smsk = 0;
+    if constexpr (S == 8) {
+        // group c = centre c of the block: this half holds slots 4h .. 4h+3, the partner half the other four
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            // this lane stores centre 2h + cc and needs the partner half's four slots of it; it sends its own slots of
+            // the centre the partner stores, 2(1-h) + cc (selects, not a per-lane register index)
+            const float mine_m = h ? gm[2 + cc] : gm[cc], send_m = h ? gm[cc] : gm[2 + cc];
+            const int mine_a = h ? ga[2 + cc] : ga[cc], send_a = h ? ga[cc] : ga[2 + cc];
+            const float pm = xor32_f(send_m, h);
+            const int pa = (int)xor32_u((unsigned int)send_a, h);
+            const float lo_m = h ? pm : mine_m, hi_m = h ? mine_m : pm;     // slots 0-3 / 4-7 in slot order
+            const int lo_a = h ? pa : mine_a, hi_a = h ? mine_a : pa;
+            float m = lo_m;
+            int a = lo_a;
+            if (hi_a >= 0 && (a < 0 || hi_m > m)) { m = hi_m; a = hi_a + 4; }
+            sval[cc] = a >= 0 ? fmaxf(m, 0.01f * m) : 0.0f;
+            smsk |= (a >= 0 ? (1u << a) : 0u) << (8 * cc);
+        }
+    } else {
+        // 16 slots: centre cb = groups 2cb, 2cb+1 of both halves; slot order: h0.g(2cb) 0-3, h1.g(2cb) 4-7, h0.g(2cb+1)
+        // 8-11, h1.g(2cb+1) 12-15.  This lane stores centre cb = h.
+        const float m0 = h ? gm[2] : gm[0], m1 = h ? gm[3] : gm[1];          // my slots of MY centre (cb = h): groups 2h, 2h+1
+        const int a0 = h ? ga[2] : ga[0], a1 = h ? ga[3] : ga[1];
+        const float s0 = h ? gm[0] : gm[2], s1 = h ? gm[1] : gm[3];          // my slots of the PARTNER's centre (1 - h)
+        const int t0 = h ? ga[0] : ga[2], t1 = h ? ga[1] : ga[3];
+        const float p0m = xor32_f(s0, h), p1m = xor32_f(s1, h);
+        const int p0a = (int)xor32_u((unsigned int)t0, h), p1a = (int)xor32_u((unsigned int)t1, h);
+        const float o_m[4] = {h ? p0m : m0, h ? m0 : p0m, h ? p1m : m1, h ? m1 : p1m};
+        const int o_a[4] = {h ? p0a : a0, h ? a0 : p0a, h ? p1a : a1, h ? a1 : p1a};
+        float m = -3.0e38f;
+        int a = -1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (o_a[t] >= 0 && (a < 0 || o_m[t] > m)) { m = o_m[t]; a = o_a[t] + 4 * t; }
+        sval[0] = a >= 0 ? fmaxf(m, 0.01f * m) : 0.0f;
+        sval[1] = 0.0f;
+        smsk = a >= 0 ? (1u << a) : 0u;
+    }
+}
+
+template <int KSTEPS, int KUSE, int S, int V = 0>
 __global__ __launch_bounds__(WS_THREADS) void edge_fwd_ws_kernel(
     EdgeGraph g, const __bf16* __restrict__ PQ, const __bf16* __restrict__ W2p, const float* __restrict__ b2,
     int H2, __bf16* __restrict__ out, long long ldo, float* __restrict__ coords, CoordCols ccols,
@@ -470,7 +566,7 @@ __global__ __launch_bounds__(WS_THREADS) void edge_fwd_ws_kernel(
     {                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
             const unsigned int co__ = (i + 1 < NI) ? (unsigned int)gc0 * 16u + 64u * i : clast;       \
-            *reinterpret_cast<u32x4*>(&As[buf_][grow * ROWB + co__]) = relu_sum_bf16x8(preg[i], qreg[i]); \
+            *reinterpret_cast<u32x4*>(&As[buf_][grow * ROWB + co__]) = act_sum_bf16x8<V>(preg[i], qreg[i]); \
         }                                                                                             \
     }
         int ic_n, jc_n;                                   // row info of the tile whose chunks are in flight
@@ -516,12 +612,13 @@ __global__ __launch_bounds__(WS_THREADS) void edge_fwd_ws_kernel(
         const __bf16* wrow = W2p + (long long)(wave * 32 + r) * K + h * 8;
 #pragma unroll
         for (int s = 0; s < KUSE; ++s) {
-            const u32x4 wv = *reinterpret_cast<const u32x4*>(wrow + s * 16) ^ (u32x4){0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+            constexpr unsigned int NEG = V == 0 ? 0x80008000u : 0u;      // the relu epilogue runs on negated weights
+            const u32x4 wv = *reinterpret_cast<const u32x4*>(wrow + s * 16) ^ (u32x4){NEG, NEG, NEG, NEG};
             w2[s] = __builtin_bit_cast(bf16x8, wv);
         }
     }
     const int col = wave * 32 + r;
-    const float bias = (col < H2) ? -b2[col] : 0.0f;     // negated bias
+    const float bias = (col < H2) ? (V == 0 ? -b2[col] : b2[col]) : 0.0f;     // negated with the weights
     int coord_d = -1;
 #pragma unroll
     for (int d = 0; d < 8; ++d)
@@ -547,6 +644,31 @@ __global__ __launch_bounds__(WS_THREADS) void edge_fwd_ws_kernel(
     }
     const unsigned int ldo32 = (unsigned int)ldo;
 
+    if constexpr (V == 1) {
+        // EdgeConvTito: plain chain, then the max / arg epilogue (no pending block, no validity fast path)
+        int bufm = 0;
+        for (; tile < tile_end; ++tile, bufm ^= 1) {
+            if (wave_on) {
+                const unsigned long long vbits = __ballot(s_jc[bufm][lane] >= 0);
+                const unsigned char* a0 = &As[bufm][r * ROWB + h * 16];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    f32x16 acc;
+                    zero_acc(acc);
+#pragma unroll
+                    for (int s = 0; s < KUSE; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(a0 + rb * 32 * ROWB + s * 32),
+                                                                      w2[s], acc, 0, 0, 0);
+                    float sval[2];
+                    unsigned int smsk;
+                    max_epi_block<S>(acc, bias, (unsigned int)(vbits >> (32 * rb + 4 * h)), h, sval, smsk);
+                    GN_WS_STORE(tile, rb, sval, smsk);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     f32x16 accP;                                     // rows 32-63 of the previous tile, epilogue pending
     zero_acc(accP);
     unsigned int vrowP = 0;
@@ -620,7 +742,7 @@ __host__ __device__ constexpr int stage_pitch(int row_bytes) {
 // accumulator (32 x NBH*32 fp32 per wave) fits the 256-VGPR budget of 2 waves/SIMD: workgroup b
 // handles k1 blocks [kb0, kb0+nblk) (kb0 = (b % HALVES) * NBH) of the tile range b / HALVES, gathers
 // only those columns of h, and writes them into slab b / HALVES.
-template <int NB1, int NBH, int HALVES, int S>   // H1p = 32 * NB1, S slots per centre
+template <int NB1, int NBH, int HALVES, int S, int V = 0>   // H1p = 32 * NB1, S slots per centre, V: 0 relu / 1 leaky relu
 __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
     EdgeGraph g, const __bf16* __restrict__ PQ, int H1, int H2,
     const __bf16* __restrict__ gout, long long ldg, const unsigned char* __restrict__ maskB,
@@ -713,9 +835,9 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
         const bool rok__ = (T_) < ntiles && rowu__ / S < g.N;                                         \
         unsigned int hb__[NI];                                                                        \
         _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
-            const u32x4 hv__ = relu_sum_bf16x8(preg[i], qreg[i]);                                     \
+            const u32x4 hv__ = act_sum_bf16x8<V>(preg[i], qreg[i]);                                   \
             *reinterpret_cast<u32x4*>(&Hs[buf_][grow * HP + (cc_[i] - cbeg) * 16]) = hv__;            \
-            hb__[i] = nonzero_bits_bf16x8(hv__);                                                      \
+            hb__[i] = V == 0 ? nonzero_bits_bf16x8(hv__) : positive_bits_bf16x8(hv__);                \
         }                                                                                             \
         if (rok__) {                                                                                  \
             const unsigned int ho__ = (unsigned int)rowu__ * (unsigned int)CHUNKS;                    \
@@ -835,7 +957,7 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
 //   * the slot sums dP[centre] = sum_slots dpre are a second, tiny MFMA: dpre^T (hardware-transposed
 //     LDS reads of the wave's own staged block) times a 0/1 slot-selection matrix, instead of 32 adds
 //     and cross-lane shuffles per lane.  (dP thus sums the bf16-rounded dpre rows: <= 1.5 bf16 ulp.)
-template <int NB1, int S>   // H1p = 32 * NB1, H2 == 256, S slots per centre
+template <int NB1, int S, int V = 0>   // H1p = 32 * NB1, H2 == 256, S slots per centre, V: 0 relu / 1 leaky relu (first layer)
 __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
     EdgeGraph g, const __bf16* __restrict__ gout, long long ldg, const unsigned char* __restrict__ maskB,
     const unsigned char* __restrict__ hbits, const __bf16* __restrict__ W2Tp,
@@ -986,7 +1108,8 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
                         const float av = acc[4 * gq + j];          // copy the element before any bit_cast
                         int m;                                     // 0 / -1 from bit 8gq+j (v_bfe_i32: one op)
                         m = __builtin_amdgcn_sbfe((int)wsh, 8 * gq + j, 1);
-                        d[j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, av) & (unsigned int)m);
+                        if constexpr (V == 0) d[j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, av) & (unsigned int)m);
+                        else d[j] = m ? av : 0.01f * av;           // leaky relu: slope 1 where h > 0, 0.01 elsewhere
                     }
                     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
                     const u32x2_t pk = {pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
@@ -1077,6 +1200,8 @@ static bool ws_enabled(int which) {
 bool edge_v2_shape_ok(int K, int H1p, int H2) {
     return K <= 16 && H2 == 256 && (H1p == 128 || H1p == 352);
 }
+// EdgeConvTito variant (leaky relu, max aggregation): the DynTrans layer sizes of the reference, (256, 256)
+bool edge_v2_max_shape_ok(int K, int H1p, int H2) { return K <= 16 && H2 == 256 && H1p == 256; }
 
 hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, const void* W2p, const float* b2, int H2,
                               void* out, long long ldo, float* coords, const CoordCols& cc, unsigned char* maskB,
@@ -1109,7 +1234,7 @@ hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, int H
 // number of slabs (= tile-range parts) the dW2 kernel writes for N nodes
 int edge_dw2_v2_parts(int N, int K, int H1p, int num_cus) {
     const long long ntiles = ((long long)N * edge_slots(K) + V2_ROWS - 1) / V2_ROWS;
-    const int halves = H1p == 352 ? 2 : 1;
+    const int halves = H1p >= 256 ? 2 : 1;
     long long parts = num_cus / halves;
     if (parts > ntiles) parts = ntiles;
     return parts > 0 ? (int)parts : 1;
@@ -1151,6 +1276,62 @@ hipError_t launch_edge_bwd_v2(const EdgeGraph& g, int H1p, int H2, const void* g
     if (H1p == 128) { if (s8) GN_BWD_LAUNCH(4, 8, 512); else GN_BWD_LAUNCH(4, 16, 512); }
     else { if (s8) GN_BWD_LAUNCH(11, 8, 704); else GN_BWD_LAUNCH(11, 16, 704); }
 #undef GN_BWD_LAUNCH
+    return hipGetLastError();
+}
+
+
+// ---- EdgeConvTito (models/components/layers.py:72-114) on the same kernels, variant V = 1 ------------------------
+// Envelope: bf16, table without overflow rows (the caller sizes K to the largest in-degree), K <= 16, H1p = H2 = 256.
+hipError_t launch_edge_max_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
+                                  void* out, long long ldo, unsigned char* maskB, int num_cus, hipStream_t st) {
+    if (!edge_v2_max_shape_ok(g.K, H1p, H2) || g.ovf_cnt) return hipErrorNotSupported;
+    if (g.N == 0) return hipSuccess;
+    if ((long long)g.N * (ldo > H2 ? ldo : H2) >= (1LL << 31) || g.N >= (1 << 24) || (long long)g.N * 4 * H1p >= (1LL << 32))
+        return hipErrorNotSupported;
+    const int ntiles = v2_tiles(g);
+    const int grid = ntiles < num_cus ? ntiles : num_cus;
+    CoordCols cc;
+    cc.n = 0;
+    for (int d = 0; d < 8; ++d) cc.c[d] = -1;
+    if (edge_slots(g.K) == 8)
+        hipLaunchKernelGGL((edge_fwd_ws_kernel<16, 16, 8, 1>), dim3(grid), dim3(WS_THREADS), 0, st, g, (const __bf16*)PQ,
+                           (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, (float*)nullptr, cc, maskB, ntiles);
+    else
+        hipLaunchKernelGGL((edge_fwd_ws_kernel<16, 16, 16, 1>), dim3(grid), dim3(WS_THREADS), 0, st, g, (const __bf16*)PQ,
+                           (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, (float*)nullptr, cc, maskB, ntiles);
+    return hipGetLastError();
+}
+hipError_t launch_edge_max_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout,
+                                  long long ldg, const unsigned char* maskB, unsigned char* hbits, float* slab,
+                                  float* db2_part, int num_cus, hipStream_t st) {
+    if (!edge_v2_max_shape_ok(g.K, H1p, H2) || g.ovf_cnt) return hipErrorNotSupported;
+    if (g.N == 0) return hipSuccess;
+    if (g.N >= (1 << 24) || (long long)g.N * 4 * H1p >= (1LL << 32) || (long long)g.N * ldg * 2 >= (1LL << 32) ||
+        (long long)g.N * H2 * 2 >= (1LL << 32) || (long long)g.N * edge_slots(g.K) * (H1p / 8) >= (1LL << 32))
+        return hipErrorNotSupported;
+    const int ntiles = v2_tiles(g);
+    const int parts = edge_dw2_v2_parts(g.N, g.K, H1p, num_cus);
+    if (edge_slots(g.K) == 8)
+        hipLaunchKernelGGL((edge_dw2_v2_kernel<8, 4, 2, 8, 1>), dim3(parts * 2), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
+                           H1, H2, (const __bf16*)gout, ldg, maskB, hbits, slab, db2_part, ntiles);
+    else
+        hipLaunchKernelGGL((edge_dw2_v2_kernel<8, 4, 2, 16, 1>), dim3(parts * 2), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
+                           H1, H2, (const __bf16*)gout, ldg, maskB, hbits, slab, db2_part, ntiles);
+    return hipGetLastError();
+}
+hipError_t launch_edge_max_bwd_v2(const EdgeGraph& g, int H1p, int H2, const void* gout, long long ldg,
+                                  const unsigned char* maskB, const unsigned char* hbits, const void* W2Tp, int H2p,
+                                  void* dpre, void* dP, long long ldp, int num_cus, hipStream_t st) {
+    if (!edge_v2_max_shape_ok(g.K, H1p, H2) || H2p != 256 || g.ovf_cnt) return hipErrorNotSupported;
+    if (g.N == 0) return hipSuccess;
+    const int ntiles = v2_tiles(g);
+    const int grid = ntiles < num_cus ? ntiles : num_cus;
+    if (edge_slots(g.K) == 8)
+        hipLaunchKernelGGL((edge_bwd_v2_kernel<8, 8, 1>), dim3(grid), dim3(512), 0, st, g, (const __bf16*)gout, ldg, maskB, hbits,
+                           (const __bf16*)W2Tp, (__bf16*)dpre, (__bf16*)dP, ldp, ntiles);
+    else
+        hipLaunchKernelGGL((edge_bwd_v2_kernel<8, 16, 1>), dim3(grid), dim3(512), 0, st, g, (const __bf16*)gout, ldg, maskB, hbits,
+                           (const __bf16*)W2Tp, (__bf16*)dpre, (__bf16*)dP, ldp, ntiles);
     return hipGetLastError();
 }
 

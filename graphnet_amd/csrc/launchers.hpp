@@ -48,6 +48,14 @@ hipError_t launch_edge_bwd(int mode, const EdgeGraph& g, const void* PQ, int H1p
 int edge_dw2_slabs(int mode, int N, int K, int H1p, int H2);
 hipError_t launch_edge_dw2(int mode, const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout,
                            long long ldg, void* saved, float* slab, float* db2_part, hipStream_t st);
+int edge_max_supported(int mode, int K, int H1p, int H2);
+int edge_max_dw2_slabs(int N, int K, int H1p);
+hipError_t launch_edge_max_fwd(const EdgeGraph& g, const void* PQ, int H1p, const void* W2p, const float* b2, int H2,
+                               void* out, long long ldo, void* saved, hipStream_t st);
+hipError_t launch_edge_max_dw2(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout, long long ldg,
+                               void* saved, float* slab, float* db2_part, hipStream_t st);
+hipError_t launch_edge_max_bwd(const EdgeGraph& g, int H1p, int H2, const void* gout, long long ldg, const void* saved,
+                               const void* W2Tp, int H2p, void* dpre, void* dP, long long ldp, hipStream_t st);
 hipError_t launch_dq_gather(int mode, const void* dpre, int H1p, const int* rev_ptr, const int* rev_rows,
                             const int* hubs, const int* nhubs, int N, void* dQ, long long ldq, hipStream_t st);
 // generic.hip

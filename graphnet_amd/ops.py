@@ -490,6 +490,64 @@ def edgeconv_dq_gather(mode: int, g: NeighbourTable, dpre: Tensor, H1p: int, dQ:
                                                     _rows(dQ, "dQ"), _st()))
 
 
+# ------------------------------------------------------------------------------ EdgeConvTito (leaky relu, max), fused
+def edgeconv_max_supported(mode: int, g: NeighbourTable, H1p: int, H2: int) -> bool:
+    """Whether the fused EdgeConvTito kernels take this layer (bf16, no overflow rows, K <= 16, H1p = H2 = 256)."""
+    return g.ovf is None and bool(_lib.lib().gn_edgeconv_max_supported(mode, g.K, H1p, H2))
+
+
+def exact_table(g: NeighbourTable) -> NeighbourTable:
+    """The same graph as a table WITHOUT overflow rows: the (k+1)-th neighbours become column K (static graphs of
+    DynEdgeTITO: built once per batch, shared by all DynTrans layers)."""
+    if g.ovf is None:
+        return g
+    nbr = torch.cat([g.nbr, g.ovf.reshape(-1, 1)], dim=1).contiguous()
+    t = NeighbourTable(nbr, None, None, None, None, g.K + 1)
+    ev = getattr(g, "event_ptr", None)
+    if ev is not None:
+        t.event_ptr = ev
+    return t
+
+
+def edgeconv_max_fwd(g: NeighbourTable, PQ: Tensor, H1p: int, W2p: Tensor, b2: Tensor, H2: int):
+    """``out[i] = leaky(max_j (leaky(P[i] + Q[j]) W2^T + b2))`` -> (out bf16 [N, H2], saved)."""
+    _need(PQ, torch.bfloat16, "PQ"); _need(W2p, torch.bfloat16, "W2p"); _need(b2, torch.float32, "b2")
+    N = g.N
+    out = torch.empty((N, H2), dtype=torch.bfloat16, device=PQ.device)
+    saved = torch.empty(int(_lib.lib().gn_edgeconv_saved_bytes(N, g.K, H1p, H2)), dtype=torch.uint8, device=PQ.device)
+    with _timed("edgeconv_fwd", f"edgeconv_max_fwd[{H1p}x{H2}]"):
+        _lib.check(_lib.lib().gn_edgeconv_max_fwd(_p(g.nbr), N, g.K, _p(PQ), H1p, _p(W2p), _p(b2), H2, _p(out),
+                                                  _rows(out, "out"), _p(saved), _st()))
+    return out, saved
+
+
+def edgeconv_max_dw2(g: NeighbourTable, PQ: Tensor, H1p: int, H1: int, H2: int, gout: Tensor, saved: Tensor):
+    """(dW2 [H2, H1], db2 [H2]); ``gout`` = d(loss)/d(out) * leaky'(out), bf16.  Must run before :func:`edgeconv_max_bwd`."""
+    L = _lib.lib()
+    _need(gout, torch.bfloat16, "gout")
+    nslab = int(L.gn_edgeconv_max_dw2_slabs(g.N, g.K, H1p))
+    dev = PQ.device
+    slab = torch.empty(nslab * H2 * H1, dtype=torch.float32, device=dev)
+    bpart = torch.empty(nslab * H2, dtype=torch.float32, device=dev)
+    with _timed("edgeconv_dw2", f"edgeconv_max_dw2[{H1p}x{H2}]"):
+        _lib.check(L.gn_edgeconv_max_dw2(_p(g.nbr), g.N, g.K, _p(PQ), H1p, H1, H2, _p(gout), _rows(gout, "gout"), _p(saved),
+                                         _p(slab), _p(bpart), _st()))
+    dW2 = torch.empty((H2, H1), dtype=torch.float32, device=dev)
+    db2 = torch.empty(H2, dtype=torch.float32, device=dev)
+    with _timed("reduce_slabs"):
+        _lib.check(L.gn_reduce_slabs(_p(slab), nslab, H2 * H1, _p(dW2), 0, _st()))
+        _lib.check(L.gn_reduce_slabs(_p(bpart), nslab, H2, _p(db2), 0, _st()))
+    return dW2, db2
+
+
+def edgeconv_max_bwd(g: NeighbourTable, H1p: int, H2: int, gout: Tensor, saved: Tensor, W2Tp: Tensor, dpre: Tensor,
+                     dP: Tensor) -> None:
+    _need(gout, torch.bfloat16, "gout"); _need(dP, torch.bfloat16, "dP"); _need(dpre, torch.bfloat16, "dpre")
+    with _timed("edgeconv_bwd", f"edgeconv_max_bwd[{H1p}x{H2}]"):
+        _lib.check(_lib.lib().gn_edgeconv_max_bwd(_p(g.nbr), g.N, g.K, H1p, H2, _p(gout), _rows(gout, "gout"), _p(saved),
+                                                  _p(W2Tp), int(W2Tp.shape[1]), _p(dpre), _p(dP), _rows(dP, "dP"), _st()))
+
+
 # ------------------------------------------------------------------------------ unfused variant blocks
 ACT_CODES = {"relu": 0, "gelu": 1, "leaky_relu": 2, "identity": 3}
 

@@ -56,16 +56,29 @@ class _DynTransFunction(torch.autograd.Function):
         Wpq[H1p:H1p + H1] = Wb + Wc
         bpq = torch.zeros(2 * H1p, dtype=torch.float32, device=dev)
         bpq[:H1] = b1
-        PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), _wt(mode, Wpq, [Fin]), 2 * H1p, bias=bpq)
-        ic, jc = ops.edge_rows(g)
         lp = mode == ops.MODE_BF16                  # GEMM-only operands are produced in bf16 (weights-stationary GEMM)
-        # leaky relu preserves the sign: a1 is produced by the gather itself and its derivative is read off a1's
-        # sign in the backward (no pre-activation tensor); the second one commutes with the max aggregation
-        a1 = ops.edge_gather_pre(PQ, H1p, ic, jc, act="leaky_relu", lowp=lp)
-        z2 = ops.linear_fwd(mode, [(a1, H1p)], _wt(mode, W2, [H1]), d, bias=b2.contiguous(), out_cols=dr)
-        conv, aux = ops.slot_reduce(z2, d, g, "max", post_act="leaky_relu")
         residual = Fin == d                                             # layers.py:183-186
-        r = conv.add_(x) if residual else conv
+        gx = cfg.get("graph_exact")
+        fused = gx is not None and ops.edgeconv_max_supported(mode, gx, H1p, d)
+        if fused:
+            # fused EdgeConvTito (csrc/edgeconv_v2.hip, variant 1): gather + leaky relu + second Linear on the matrix
+            # core + max / arg-slot epilogue in one persistent kernel; no edge-row tensor reaches HBM
+            PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), _wt(mode, Wpq, [Fin]), 2 * H1p, bias=bpq, out_lowp=True)
+            conv16, esaved = ops.edgeconv_max_fwd(gx, PQ, H1p, ops.pack_weight(W2, [H1], torch.bfloat16), b2.contiguous(), d)
+            r = torch.empty((N, d), dtype=torch.float32, device=dev)
+            ops.dropout(conv16, 0, 0, res=x.contiguous() if residual else None, out=r)     # r = (x +) conv, fp32
+            a1 = z2 = aux = None
+        else:
+            PQ = ops.linear_fwd(mode, _ksegs([(xin, Fin)]), _wt(mode, Wpq, [Fin]), 2 * H1p, bias=bpq)
+            ic, jc = ops.edge_rows(g)
+            # leaky relu preserves the sign: a1 is produced by the gather itself and its derivative is read off a1's
+            # sign in the backward (no pre-activation tensor); the second one commutes with the max aggregation
+            a1 = ops.edge_gather_pre(PQ, H1p, ic, jc, act="leaky_relu", lowp=lp)
+            z2 = ops.linear_fwd(mode, [(a1, H1p)], _wt(mode, W2, [H1]), d, bias=b2.contiguous(), out_cols=dr)
+            conv, aux = ops.slot_reduce(z2, d, g, "max", post_act="leaky_relu")
+            r = conv.add_(x) if residual else conv
+            conv16 = esaved = None
+            PQ = None
         y0, st0 = ops.rownorm_act_fwd(r, d, "identity", g0, be0, lowp="both" if lp else "no")      # self.norm1
         y0, y0g = y0 if lp else (y0, y0)            # fp32 for the residual stream, bf16 copy for the GEMMs
         # --- TransformerEncoderLayer, norm_first=False
@@ -95,6 +108,7 @@ class _DynTransFunction(torch.autograd.Function):
         y2, st2 = ops.rownorm_act_fwd(z3, d, "identity", g2, be2)
         ctx.cfg, ctx.p = cfg, p
         ctx.saved = (xin, Fin, a1, z2, aux, residual, r, st0, y0g, qkv, att, lse2, z1, st1, y1g, h, z3, st2)
+        ctx.fused = (PQ, conv16, esaved) if fused else None
         return y2
 
     @staticmethod
@@ -137,16 +151,27 @@ class _DynTransFunction(torch.autograd.Function):
         # DynTrans.norm1
         dres, grads[4], grads[5] = ops.rownorm_act_bwd(dz1, r, d, "identity", g0, be0, st0)
         # EdgeConvTito
-        ic, jc = ops.edge_rows(g)
-        dz2, _, _ = ops.rownorm_act_bwd(dres, z2, d, "leaky_relu", valid=jc, gidx=ic, argrow=aux[1], cpad=dr,
-                                        lowp="only" if lp else "no")        # max routing + leaky' in one pass
-        dW2, grads[3] = ops.linear_wgrad(mode, dz2, d, [(a1, H1p)], with_bias=True)
-        grads[2] = dW2[:, :H1]
-        da1 = ops.linear_fwd(mode, _ksegs([(dz2, d)]), _wt(mode, W2.t(), [d]), H1, out_cols=H1p)
-        dpre1, _, _ = ops.rownorm_act_bwd(da1, a1, H1, "leaky_relu", valid=jc, cpad=H1p)
-        dPQ = torch.empty((N, 2 * H1p), dtype=torch.float32, device=dev)
-        dPQ[:, :H1p] = ops.slot_sum(dpre1, H1p, g)
-        ops.edgeconv_dq_gather(ops.MODE_F32, g, dpre1, H1p, dPQ[:, H1p:])
+        if ctx.fused is not None:
+            PQ, conv16, esaved = ctx.fused
+            gx = cfg["graph_exact"]
+            # d(loss)/d(max) = dres * leaky'(out): read off the sign of the stored (bf16) output
+            gmax, _, _ = ops.rownorm_act_bwd(dres, conv16, d, "leaky_relu", cpad=d, lowp="only")
+            grads[2], grads[3] = ops.edgeconv_max_dw2(gx, PQ, H1p, H1, d, gmax, esaved)      # also records h > 0 bits
+            dPQ = torch.empty((N, 2 * H1p), dtype=torch.bfloat16, device=dev)
+            dpre1 = torch.empty((max(gx.rows, 1), H1p), dtype=torch.bfloat16, device=dev)
+            ops.edgeconv_max_bwd(gx, H1p, d, gmax, esaved, ops.pack_weight(W2.t(), [d], torch.bfloat16), dpre1, dPQ[:, :H1p])
+            ops.edgeconv_dq_gather(ops.MODE_BF16, gx, dpre1, H1p, dPQ[:, H1p:])
+        else:
+            ic, jc = ops.edge_rows(g)
+            dz2, _, _ = ops.rownorm_act_bwd(dres, z2, d, "leaky_relu", valid=jc, gidx=ic, argrow=aux[1], cpad=dr,
+                                            lowp="only" if lp else "no")        # max routing + leaky' in one pass
+            dW2, grads[3] = ops.linear_wgrad(mode, dz2, d, [(a1, H1p)], with_bias=True)
+            grads[2] = dW2[:, :H1]
+            da1 = ops.linear_fwd(mode, _ksegs([(dz2, d)]), _wt(mode, W2.t(), [d]), H1, out_cols=H1p)
+            dpre1, _, _ = ops.rownorm_act_bwd(da1, a1, H1, "leaky_relu", valid=jc, cpad=H1p)
+            dPQ = torch.empty((N, 2 * H1p), dtype=torch.float32, device=dev)
+            dPQ[:, :H1p] = ops.slot_sum(dpre1, H1p, g)
+            ops.edgeconv_dq_gather(ops.MODE_F32, g, dpre1, H1p, dPQ[:, H1p:])
         dWpq, dbpq = ops.linear_wgrad(mode, dPQ, 2 * H1p, _ksegs([(xin, Fin)]), with_bias=True)
         dWpq = dWpq[:, :Fin]
         dWp, dWq = dWpq[:H1], dWpq[H1p:H1p + H1]
@@ -356,7 +381,12 @@ class DynEdgeTITO(GNN):
         plan = ops.attention_plan(ptr32)
         gv = ops.graph_globals(x, ptr32, table, n_pulses) if self._use_global_features else None
         seed_log: List[List[int]] = []
-        cfg = {"mode": self._compute_mode, "graph": table, "ptr": ptr32, "batch": batch32, "plan": plan,
+        # static graph: one table without overflow rows for the fused EdgeConvTito kernels (bf16 mode), shared by all
+        # DynTrans layers; its reverse lists are built once
+        exact = ops.exact_table(table) if self._compute_mode == ops.MODE_BF16 and getattr(self, "_fused_edges", True) else None
+        if exact is not None and exact.K > 16:
+            exact = None
+        cfg = {"mode": self._compute_mode, "graph": table, "graph_exact": exact, "ptr": ptr32, "batch": batch32, "plan": plan,
                "seed_log": seed_log if return_trace else None}
         conv_out = []
         for conv in self._conv_layers:

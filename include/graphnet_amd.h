@@ -35,7 +35,7 @@ extern "C" {
 #define GN_MAXSEG 6
 
 const char* gn_last_error(void);
-#define GN_ABI_VERSION 2   /* 2: gn_edgeconv_fwd takes the real hidden width H1 */
+#define GN_ABI_VERSION 3   /* 2: gn_edgeconv_fwd takes the real hidden width H1; 3: gn_edgeconv_max_* (EdgeConvTito) */
 int gn_abi_version(void);   /* == GN_ABI_VERSION of the header the library was built from */
 
 /* ---- graph construction ------------------------------------------------------------- */
@@ -160,6 +160,25 @@ int gn_edgeconv_bwd(int32_t mode, const int32_t* nbr, const int32_t* ovf_centre,
                     const int32_t* ovf_cnt, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H2,
                     const void* gout, int64_t ldg, const void* saved, const void* W2Tp, int32_t H2p,
                     void* dpre, void* dP, int64_t ldp, void* stream);
+/* EdgeConvTito (models/components/layers.py:72-114: message nn([x_i, x_j - x_i, x_j]) with LeakyReLU after both Linear
+ * layers, MAX aggregation; replaces PyG's EdgeConv.propagate + scatter-max and their backward) fused like the relu / add
+ * variant above: out[i] = leaky(max_j (leaky(P[i] + Q[j]) W2^T + b2)), per (centre, column) the slot that supplied the
+ * maximum is kept as a one-hot slot mask, and the backward kernels route the gradient to that edge row only.
+ * bf16 mode, tables WITHOUT overflow rows (size K to the largest in-degree), K <= 16, H1p = H2 = 256 (the DynTrans
+ * layer sizes of the reference: dynedge_kaggle_tito.py:44-47); gn_edgeconv_max_supported() says whether a shape is
+ * inside that envelope - outside it the entry points return an error and the caller uses the unfused edge-row ops.
+ * saved: gn_edgeconv_saved_bytes(N, K, H1p, H2) bytes; gout of gn_edgeconv_max_dw2 / _bwd must already hold
+ * d(loss)/d(out) * leaky'(out) (gn_rownorm_act_bwd does that); slab: gn_edgeconv_max_dw2_slabs() * H2 * H1 floats,
+ * db2_part: gn_edgeconv_max_dw2_slabs() * H2 floats (reduce with gn_reduce_slabs); dpre rows bf16[N*S, H1p]. */
+int32_t gn_edgeconv_max_supported(int32_t mode, int32_t K, int32_t H1p, int32_t H2);
+int32_t gn_edgeconv_max_dw2_slabs(int32_t N, int32_t K, int32_t H1p);
+int gn_edgeconv_max_fwd(const int32_t* nbr, int32_t N, int32_t K, const void* PQ, int32_t H1p, const void* W2p,
+                        const float* b2, int32_t H2, void* out, int64_t ldo, void* saved, void* stream);
+int gn_edgeconv_max_dw2(const int32_t* nbr, int32_t N, int32_t K, const void* PQ, int32_t H1p, int32_t H1, int32_t H2,
+                        const void* gout, int64_t ldg, void* saved, float* slab, float* db2_part, void* stream);
+int gn_edgeconv_max_bwd(const int32_t* nbr, int32_t N, int32_t K, int32_t H1p, int32_t H2, const void* gout, int64_t ldg,
+                        const void* saved, const void* W2Tp, int32_t H2p, void* dpre, void* dP, int64_t ldp, void* stream);
+
 /* dQ[j] (T[N, ldq]) = sum of dpre rows that gathered from j (ascending row id, fp32 accumulation).
  * hubs / nhubs (optional, may be NULL): what gn_rev_build leaves in its `cursor` / `tmp[0]` workspace - the
  * nodes with 65..16384 in-edges (sorted lists); they are then summed by a 16-wave workgroup each, in a

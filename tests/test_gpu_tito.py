@@ -148,6 +148,42 @@ def test_dynedge_tito_forward_backward(oracle, name, mode, tol, dropout):
             assert norm_err(p.grad, po.grad) < 1.2e-1, f"{name}: grad {kn}"
 
 
+def test_dynedge_tito_fused_edge_kernels_in_the_model(oracle):
+    """The reference's DynTrans layer sizes (256, 256) (``dynedge_kaggle_tito.py:44-47``) in bf16 mode take the FUSED
+    EdgeConvTito kernels (csrc/edgeconv_v2.hip variant 1); smaller layers (the test above) the unfused edge-row ops.
+    Same gates as there: outputs 3e-2, gradients 1.2e-1 in Frobenius norm; and the fused path is actually taken."""
+    from graphnet_amd import ops
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    b = synthetic_icecube86_batch(7, seed=17)
+    b.x[3:16, :3] = b.x[2, :3]          # duplicate positions: (k+1)-th neighbours -> 9 table columns, 16 slots
+    kw = dict(dyntrans_layer_sizes=[(256, 256), (256, 256)], post_processing_layer_sizes=[48, 32],
+              readout_layer_sizes=[32, 16], global_pooling_schemes=["max", "mean"], n_head=8)
+    m, ref = _tito_pair("bf16", dropout=0.0, **kw)
+    ei = oracle.knn_graph(b.x, 8, b.batch, [0, 1, 2])
+    m.train()
+    ops.enable_timers(True)
+    y, tr = m(b.to(DEV), return_trace=True)
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+    (y * w.to(DEV)).sum().backward()
+    used = ops.timer_summary(detail=True)
+    ops.enable_timers(False)
+    assert used.get("edgeconv_max_fwd[256x256]", (0, 0))[0] == 2 and used.get("edgeconv_max_bwd[256x256]", (0, 0))[0] == 2
+    b = b.to("cpu")
+    yo, tro = ref(b.x, ei, b.batch, b.n_pulses, return_trace=True, drop=None)
+    (yo * w).sum().backward()
+    for l, (a, ao) in enumerate(zip(tr["conv_out"], tro["conv_out"])):
+        assert rel_err(a, ao.detach()) < 3e-2, f"DynTrans layer {l}"
+    assert rel_err(y, yo.detach()) < 3e-2
+    for (kn, p), (_, po) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, kn
+        assert norm_err(p.grad, po.grad) < 1.2e-1, f"grad {kn}"
+    # the unfused path on the same model and batch gives the same answer to bf16 rounding
+    m._fused_edges = False
+    m.zero_grad()
+    y2 = m(b.to(DEV))
+    assert rel_err(y2, y.detach()) < 3e-2
+
+
 def test_dynedge_tito_state_dict_and_eval_mode():
     import graphnet_amd as g
     from oracle import tito_oracle
@@ -259,3 +295,64 @@ def test_batchnorm_rows_edge_cases():
             assert torch.allclose(mean, z[0], atol=1e-6) and torch.allclose(a[0], torch.relu(bet), atol=1e-3)
         dz, dg, db = ops.bn_act_bwd(torch.ones_like(z), z, C, valid, mean, rstd, gam, bet, "relu", nv)
         assert torch.isfinite(dz).all() and torch.isfinite(dg).all() and torch.isfinite(db).all()
+
+
+@pytest.mark.parametrize("k", [8, 5])
+def test_fused_edgeconv_tito_kernels_equal_the_unfused_ops(k):
+    """EdgeConvTito (``components/layers.py:72-114``) fused (csrc/edgeconv_v2.hip, variant 1: gather + leaky relu +
+    matrix-core GEMM + max / arg-slot epilogue; arg-routed backward) against the unfused edge-row ops of
+    csrc/generic.hip, which the model tests pin to ``oracle/tito_oracle.py``: same bf16-rounded operands, outputs within
+    bf16 rounding (2e-2 of the tensor's max), gradients within 2e-2 in Frobenius norm (a near-tie may route one
+    column's gradient to another edge).  k = 8 in compat mode has (k+1)-th neighbours -> 9 columns, S = 16 slots;
+    k = 5 -> 6 columns, S = 8 slots; events of 1 and 3 pulses have empty and short neighbour lists."""
+    from graphnet_amd import ops
+    from graphnet_amd.synthetic import synthetic_icecube86_batch
+    from graphnet_amd.data import Batch, Data
+    mode = ops.MODE_BF16
+    big = synthetic_icecube86_batch(20, seed=4)
+    parts = [Data(x=big.x[big.ptr[i]:big.ptr[i + 1]], n_pulses=big.n_pulses[i]) for i in range(20)]
+    parts.insert(3, Data(x=big.x[:1].clone(), n_pulses=torch.tensor(1, dtype=torch.int32)))      # an isolated pulse
+    parts.insert(9, Data(x=big.x[5:8].clone(), n_pulses=torch.tensor(3, dtype=torch.int32)))     # degree 2
+    b = Batch.from_data_list(parts).to(DEV)
+    N = int(b.x.shape[0])
+    ptr32, batch32 = b.ptr.to(torch.int32), b.batch.to(torch.int32)
+    g = ops.exact_table(ops.knn_graph(b.x, [0, 1, 2], batch32, ptr32, k))
+    assert g.ovf is None and g.K == k + 1
+    H1 = H1p = d = 256
+    assert ops.edgeconv_max_supported(mode, g, H1p, d)
+    torch.manual_seed(11)
+    PQ16 = (torch.randn(N, 2 * H1p, device=DEV) * 0.7).bfloat16()
+    W2 = torch.randn(d, H1, device=DEV) * 0.06
+    b2 = torch.randn(d, device=DEV) * 0.2
+    gout = torch.randn(N, d, device=DEV)
+    # ---- fused
+    out16, saved = ops.edgeconv_max_fwd(g, PQ16, H1p, ops.pack_weight(W2, [H1], torch.bfloat16), b2, d)
+    gmax, _, _ = ops.rownorm_act_bwd(gout, out16, d, "leaky_relu", cpad=d, lowp="only")
+    dW2_f, db2_f = ops.edgeconv_max_dw2(g, PQ16, H1p, H1, d, gmax, saved)
+    dPQ_f = torch.zeros((N, 2 * H1p), dtype=torch.bfloat16, device=DEV)
+    dpre = torch.empty((g.rows, H1p), dtype=torch.bfloat16, device=DEV)
+    ops.edgeconv_max_bwd(g, H1p, d, gmax, saved, ops.pack_weight(W2.t().contiguous(), [d], torch.bfloat16), dpre, dPQ_f[:, :H1p])
+    ops.edgeconv_dq_gather(mode, g, dpre, H1p, dPQ_f[:, H1p:])
+    out16_b, _ = ops.edgeconv_max_fwd(g, PQ16, H1p, ops.pack_weight(W2, [H1], torch.bfloat16), b2, d)
+    assert torch.equal(out16, out16_b), "the fused forward must be bitwise reproducible"
+    # ---- unfused on the same bf16-representable operands
+    ic, jc = ops.edge_rows(g)
+    a1 = ops.edge_gather_pre(PQ16.float(), H1p, ic, jc, act="leaky_relu", lowp=True)
+    z2 = ops.linear_fwd(mode, [(a1, H1p)], ops.pack_weight(W2, [H1], torch.bfloat16, ops.gemm_kunit(mode)), d, bias=b2,
+                        out_cols=d)
+    conv, aux = ops.slot_reduce(z2, d, g, "max", post_act="leaky_relu")
+    dz2, _, _ = ops.rownorm_act_bwd(gout, z2, d, "leaky_relu", valid=jc, gidx=ic, argrow=aux[1], cpad=d, lowp="only")
+    dW2_u, db2_u = ops.linear_wgrad(mode, dz2, d, [(a1, H1p)], with_bias=True)
+    da1 = ops.linear_fwd(mode, [(dz2, d)], ops.pack_weight(W2.t().contiguous(), [d], torch.bfloat16, ops.gemm_kunit(mode)),
+                         H1, out_cols=H1p)
+    dpre_u, _, _ = ops.rownorm_act_bwd(da1, a1, H1, "leaky_relu", valid=jc, cpad=H1p)
+    dP_u = ops.slot_sum(dpre_u, H1p, g)
+    dQ_u = torch.zeros((N, H1p), dtype=torch.float32, device=DEV)
+    ops.edgeconv_dq_gather(ops.MODE_F32, g, dpre_u, H1p, dQ_u)
+    torch.cuda.synchronize()
+    assert rel_err(out16.float(), conv) < 2e-2
+    iso = int(b.ptr[3])                                       # the single-pulse event: no neighbours -> exactly 0
+    assert float(out16[iso].float().abs().max()) == 0.0 and float(conv[iso].abs().max()) == 0.0
+    assert norm_err(dW2_f, dW2_u[:, :H1]) < 2e-2 and norm_err(db2_f, db2_u) < 2e-2
+    assert norm_err(dPQ_f[:, :H1p].float(), dP_u) < 2e-2
+    assert norm_err(dPQ_f[:, H1p:].float(), dQ_u) < 2e-2
