@@ -227,7 +227,10 @@ class _PostPoolFunction(torch.autograd.Function):
         for t in reversed(range(nl)):
             W = params[2 * t]
             Pt, Pin = int(W.shape[0]), int(W.shape[1])
-            dz, _, _ = ops.rownorm_act_bwd(gy.contiguous(), zs[t], Pt, "leaky_relu", cpad=ops.round_up(Pt, 8))
+            # dz is only ever a GEMM operand (weight gradient, input gradient): bf16 in bf16 mode, as the MFMA would
+            # round it anyway - and bf16 dY carries the bias gradient as a ones block of the same GEMM
+            dz, _, _ = ops.rownorm_act_bwd(gy.contiguous(), zs[t], Pt, "leaky_relu", cpad=ops.round_up(Pt, 8),
+                                           lowp="only" if mode == ops.MODE_BF16 else "no")
             if t > 0:
                 yprev, _ = ops.rownorm_act_fwd(zs[t - 1], Pin, "leaky_relu", cpad=ops.round_up(Pin, 8))
                 in_segs = [(yprev, Pin)]

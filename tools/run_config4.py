@@ -40,7 +40,28 @@ torch.cuda.synchronize()
 n = b.n_pulses.double()
 print(f"config4 dropout={p_drop} B={B} N={b.x.shape[0]} (pulses/event {int(n.min())}..{int(n.max())}, sum n^2 = {float((n*n).sum()):.3g}) {dtype}: "
       f"{1e3*dt:.1f} ms/step  {B/dt:.1f} events/s  {b.x.shape[0]/dt/1e6:.2f} Mpulses/s  loss {float(l):.4f}")
-print({k: round(ms / steps, 3) for k, (n_, ms) in ops.timer_summary().items()})
+summary = ops.timer_summary()
+print({k: round(ms / steps, 3) for k, (n_, ms) in summary.items()})
+# one JSON line in the shape of bench.py's (BASELINE configs[3] has no bench.py leg): throughput + the roofline of the
+# dominant kernel family, the ragged self attention, priced at 4 * sum(n_i^2) * d_model FLOP per layer forward
+# (Q K^T and P V, 2 FLOP per MAC) and 2.5x that backward (dQ, dK, dV, dP recomputation), against the dense bf16 peak
+import json
+sn2, dmod, layers = float((n * n).sum()), 256, 4
+f_fwd, f_bwd = 4.0 * sn2 * dmod * layers, 10.0 * sn2 * dmod * layers
+t_fwd = summary.get("attention_fwd", (0, 0.0))[1] / steps * 1e-3
+t_bwd = summary.get("attention_bwd", (0, 0.0))[1] / steps * 1e-3
+print(json.dumps({
+    "metric": "events/sec DynEdgeTITO fwd+bwd+Adam, mixed 50-3000 pulses/event, k=8 static edges", "value": B / dt,
+    "unit": "events/s", "n_gpus": 1, "steps": steps, "ms_per_step": 1e3 * dt, "dtype": dtype, "data": "synthetic",
+    "config": {"workload": "configs[3]: DynEdgeTITO 4 x (256, 256), 8 heads, FFN 2048, IceCube-86 geometry, "
+                           "pulses per event log-uniform 50..3000", "events_per_gpu": B, "pulses_per_gpu": int(b.x.shape[0]),
+               "sum_n2": sn2, "dropout": p_drop},
+    "roofline": {"bound": "mfma", "kernel": "attn_fwd_mfma + attn_bwd_dq_mfma + attn_bwd_dkv_mfma (4 layers)",
+                 "achieved": (f_fwd + f_bwd) / max(t_fwd + t_bwd, 1e-9) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                 "frac": (f_fwd + f_bwd) / max(t_fwd + t_bwd, 1e-9) / 1e12 / 2500.0,
+                 "fwd_tflops": f_fwd / max(t_fwd, 1e-9) / 1e12, "bwd_tflops": f_bwd / max(t_bwd, 1e-9) / 1e12,
+                 "launch_ms_fwd": 1e3 * t_fwd / layers, "launch_ms_bwd": 1e3 * t_bwd / layers, "traffic": None},
+    "phase_ms_per_step": {k: ms / steps for k, (n_, ms) in sorted(summary.items(), key=lambda kv: -kv[1][1])}}))
 if "--cpu-baseline" in sys.argv:     # the oracle (CPU restatement, test infrastructure) timed on a bounded sample
     from oracle import dynedge_oracle, tito_oracle
     nb = 8
