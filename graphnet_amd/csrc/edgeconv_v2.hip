@@ -523,7 +523,7 @@ template <int KSTEPS, int KUSE, int S, int V = 0>
 __global__ __launch_bounds__(WS_THREADS) void edge_fwd_ws_kernel(
     EdgeGraph g, const __bf16* __restrict__ PQ, const __bf16* __restrict__ W2p, const float* __restrict__ b2,
     int H2, __bf16* __restrict__ out, long long ldo, float* __restrict__ coords, CoordCols ccols,
-    unsigned char* __restrict__ maskB, int ntiles)
+    unsigned char* __restrict__ maskB, int ntiles, int producers_first)
 {
     static_assert(S == 8 || S == 16, "8 or 16 slots per centre");
     constexpr int NST = 16 / S;
@@ -533,7 +533,11 @@ __global__ __launch_bounds__(WS_THREADS) void edge_fwd_ws_kernel(
     __shared__ __attribute__((aligned(16))) unsigned char As[2][V2_ROWS * ROWB];
     __shared__ int s_jc[2][V2_ROWS];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // producers_first (A/B switch GN_WS_PRODUCERS_FIRST): the producer role goes to waves 0-3 (the OLDEST waves of the
+    // workgroup win the vector-issue arbitration of their SIMD) instead of 8-11; `wave` below is the role index:
+    // 0-7 consumers, 8-11 producers, whichever hardware waves play them
+    const int tid = threadIdx.x, lane = tid & 63, hw_wave = tid >> 6;
+    const int wave = producers_first ? (hw_wave < 4 ? hw_wave + 8 : hw_wave - 4) : hw_wave;
     const long long main_rows = (long long)g.N * S;
     const int kslots = g.K;
     const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(WS_THREADS) void edge_fwd_ws_kernel(
     if (wave >= 8) {
         // ------------------------------------------------------------------ producer
         constexpr int NI = (CHUNKS + 3) / 4;             // 16-byte chunks per thread (4 threads per row)
-        const int ptid = tid - 512;
+        const int ptid = (wave - 8) * 64 + lane;
         const int grow = ptid >> 2, gc0 = ptid & 3;
         u32x4 preg[NI], qreg[NI];
         // 32-bit byte offsets off the uniform base; chunk i sits at the immediate offset 64 * i from the thread's first
@@ -1197,6 +1201,11 @@ static bool ws_enabled(int which) {
     }
     return (mask >> which) & 1;
 }
+static int ws_producers_first() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GN_WS_PRODUCERS_FIRST"); v = e ? atoi(e) : 1; }
+    return v;
+}
 bool edge_v2_shape_ok(int K, int H1p, int H2) {
     return K <= 16 && H2 == 256 && (H1p == 128 || H1p == 352);
 }
@@ -1215,7 +1224,7 @@ hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, int H
                        (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, coords, cc, maskB, ntiles)
 #define GN_FWD_LAUNCH_WS(KS, KU, SS)                                                                       \
     hipLaunchKernelGGL((edge_fwd_ws_kernel<KS, KU, SS>), dim3(grid), dim3(WS_THREADS), 0, st, g, (const __bf16*)PQ,  \
-                       (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, coords, cc, maskB, ntiles)
+                       (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, coords, cc, maskB, ntiles, ws_producers_first())
     const bool s8 = edge_slots(g.K) == 8;
     if (ws_enabled(0) && (long long)g.N * (ldo > H2 ? ldo : H2) < (1LL << 31) && g.N < (1 << 24) &&
         (long long)g.N * 4 * H1p < (1LL << 32)) {                                    // 32-bit offsets, 24-bit node ids
@@ -1295,10 +1304,10 @@ hipError_t launch_edge_max_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, c
     for (int d = 0; d < 8; ++d) cc.c[d] = -1;
     if (edge_slots(g.K) == 8)
         hipLaunchKernelGGL((edge_fwd_ws_kernel<16, 16, 8, 1>), dim3(grid), dim3(WS_THREADS), 0, st, g, (const __bf16*)PQ,
-                           (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, (float*)nullptr, cc, maskB, ntiles);
+                           (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, (float*)nullptr, cc, maskB, ntiles, ws_producers_first());
     else
         hipLaunchKernelGGL((edge_fwd_ws_kernel<16, 16, 16, 1>), dim3(grid), dim3(WS_THREADS), 0, st, g, (const __bf16*)PQ,
-                           (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, (float*)nullptr, cc, maskB, ntiles);
+                           (const __bf16*)W2p, b2, H2, (__bf16*)out, ldo, (float*)nullptr, cc, maskB, ntiles, ws_producers_first());
     return hipGetLastError();
 }
 hipError_t launch_edge_max_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H1, int H2, const void* gout,
