@@ -73,6 +73,7 @@ int gn_rev_build(const int32_t* nbr, int32_t N, int32_t K, const int32_t* ovf_sr
     return fail(gn::launch_rev_build(nbr, N, K, gn::edge_slots(K), ovf_src, ovf_cnt, rev_ptr, cursor, tmp, rev_rows,
                                      S(stream)), "gn_rev_build");
 }
+int32_t gn_rev_event_slices(int32_t B) { return gn::rev_event_slices(B); }
 int gn_rev_build_events(const int32_t* nbr, int32_t N, int32_t K, const int32_t* ovf, const int32_t* ovf_pos,
                         const int32_t* ptr, int32_t B, int32_t* rev_ptr, int32_t* rev_rows, int32_t* ev, int32_t* scratch,
                         int32_t* hubs, int32_t* nhubs, int32_t* tmp, void* stream) {

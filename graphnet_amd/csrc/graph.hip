@@ -696,93 +696,130 @@ hipError_t launch_ovf_compact(const int* ovf, int N, int* flag_pos /*[N]*/, int*
 // the neighbour table twice instead of the global path's count / scan / fill / hub search over N atomics in HBM.
 // ovf[i] = source of centre i's (k+1)-th edge or -1; ovf_pos[i] = index of that overflow row (row id N*S + ovf_pos[i]).
 constexpr int REV_EV_CAP = 8192;
+// Scan of the table entries [a, b) of an event by the 256 threads of a workgroup: the loads of 4 x 4 entries are issued
+// before any is looked at (the body has a data-dependent branch; one load per iteration left every wave waiting a
+// full L2 round trip per entry: 0.53 ms for the 1.7e5 entries of a 10^4-pulse event).
+#define GN_SCAN_TABLE(nbr_, a_, b_, tid_, ...)                                                        \
+    {                                                                                                 \
+        const long long a__ = (a_), b__ = (b_);                                                       \
+        const long long a4__ = (a__ + 3) & ~3ll;                     /* first 16-byte aligned entry */ \
+        for (long long t = a__ + (tid_); t < (a4__ < b__ ? a4__ : b__); t += 256) { const int j = (nbr_)[t]; __VA_ARGS__ }          \
+        for (long long t0 = a4__ + 4ll * (tid_); t0 < b__; t0 += 4ll * 256 * 4) {                     \
+            int4 v__[4];                                                                              \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
+                const long long tu = t0 + 4ll * 256 * u;                                              \
+                v__[u] = make_int4(-1, -1, -1, -1);                                                   \
+                if (tu + 3 < b__) v__[u] = *reinterpret_cast<const int4*>((nbr_) + tu);               \
+                else if (tu < b__) { v__[u].x = (nbr_)[tu]; if (tu + 1 < b__) v__[u].y = (nbr_)[tu + 1]; if (tu + 2 < b__) v__[u].z = (nbr_)[tu + 2]; } \
+            }                                                                                         \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
+                const long long tu = t0 + 4ll * 256 * u;                                              \
+                { const long long t = tu; const int j = v__[u].x; if (t < b__) { __VA_ARGS__ } }             \
+                { const long long t = tu + 1; const int j = v__[u].y; if (t < b__) { __VA_ARGS__ } }         \
+                { const long long t = tu + 2; const int j = v__[u].z; if (t < b__) { __VA_ARGS__ } }         \
+                { const long long t = tu + 3; const int j = v__[u].w; if (t < b__) { __VA_ARGS__ } }         \
+            }                                                                                         \
+        }                                                                                             \
+    }
+
+// NSL > 1: the sources of an event are cut into NSL contiguous slices and workgroup (e, sl) = blockIdx.x = e * NSL + sl
+// builds the lists of slice sl only, scanning ALL rows of its event (redundant reads of the small neighbour table, no
+// communication between the slices).  A batch of a few huge events (BASELINE configs[4]: 16 x 10^4 pulses) then
+// still fills the chip; with one workgroup per event it ran on 16 CUs, and the global path (N*S contended atomics on
+// hub pulses) took 0.93 ms per graph.
 __global__ __launch_bounds__(256) void rev_event_count(const int* __restrict__ nbr, const int* __restrict__ ovf,
-                                                      const int* __restrict__ ptr, int K, int* __restrict__ ev_edges,
+                                                      const int* __restrict__ ptr, int K, int NSL, int* __restrict__ ev_edges,
                                                       int* __restrict__ nhubs) {
     __shared__ int red[4];
-    const int e = blockIdx.x, lo = ptr[e], hi = ptr[e + 1];
+    const int e = (int)blockIdx.x / NSL, sl = (int)blockIdx.x % NSL, lo = ptr[e], hi = ptr[e + 1];
+    const int per = (max(hi - lo, 0) + NSL - 1) / NSL;
+    const int j0 = lo + sl * per, j1 = min(j0 + per, hi);          // sources of this slice
     int c = 0;
-    for (long long t = (long long)lo * K + threadIdx.x; t < (long long)hi * K; t += 256) c += nbr[t] >= 0 ? 1 : 0;
-    if (ovf)
-        for (int i = lo + threadIdx.x; i < hi; i += 256) c += ovf[i] >= 0 ? 1 : 0;
+    // (NSL == 1: [j0, j1) is the whole event and every entry >= 0 lies in it - edges never leave an event)
+    GN_SCAN_TABLE(nbr, (long long)lo * K, (long long)hi * K, threadIdx.x, { (void)t; c += (j >= j0 && j < j1) ? 1 : 0; });
+    if (ovf) GN_SCAN_TABLE(ovf, (long long)lo, (long long)hi, threadIdx.x, { (void)t; c += (j >= j0 && j < j1) ? 1 : 0; });
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
-        ev_edges[e] = (red[0] + red[1]) + (red[2] + red[3]);
-        if (e == 0) *nhubs = 0;
+        ev_edges[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (blockIdx.x == 0) *nhubs = 0;
     }
 }
 __global__ __launch_bounds__(256) void rev_event_build(const int* __restrict__ nbr, const int* __restrict__ ovf,
                                                       const int* __restrict__ ovf_pos, const int* __restrict__ ptr,
-                                                      const int* __restrict__ ev_base, int B, int N, int K, int S,
+                                                      const int* __restrict__ ev_base, int B, int N, int K, int S, int NSL,
                                                       int* __restrict__ rev_ptr, int* __restrict__ rev_rows,
                                                       int* __restrict__ scratch, int* __restrict__ hubs,
                                                       int* __restrict__ nhubs) {
     __shared__ int lds_cnt[REV_EV_CAP];
     __shared__ int chunk_sum[256];
-    const int e = blockIdx.x, lo = ptr[e], hi = ptr[e + 1], n = hi - lo, tid = threadIdx.x;
-    const int base = ev_base[e];
-    if (e == B - 1 && tid == 0) rev_ptr[N] = ev_base[B];
+    const int e = (int)blockIdx.x / NSL, sl = (int)blockIdx.x % NSL, lo = ptr[e], hi = ptr[e + 1], tid = threadIdx.x;
+    const int base = ev_base[blockIdx.x];
+    if ((int)blockIdx.x == B * NSL - 1 && tid == 0) rev_ptr[N] = ev_base[B * NSL];
+    const int per = (max(hi - lo, 0) + NSL - 1) / NSL;
+    const int j0 = lo + sl * per, j1 = min(j0 + per, hi);          // sources of this slice: [j0, j1)
+    const int n = j1 - j0;
     if (n <= 0) return;
-    int* cnt = n <= REV_EV_CAP ? lds_cnt : scratch + lo;       // workgroup-uniform
+    int* cnt = n <= REV_EV_CAP ? lds_cnt : scratch + j0;       // workgroup-uniform
     for (int j = tid; j < n; j += 256) cnt[j] = 0;
     __syncthreads();
-    for (long long t = (long long)lo * K + tid; t < (long long)hi * K; t += 256) {
-        const int j = nbr[t];
-        if (j >= 0) atomicAdd(&cnt[j - lo], 1);
-    }
-    if (ovf)
-        for (int i = lo + tid; i < hi; i += 256) { const int j = ovf[i]; if (j >= 0) atomicAdd(&cnt[j - lo], 1); }
+    GN_SCAN_TABLE(nbr, (long long)lo * K, (long long)hi * K, tid, { (void)t; if (j >= j0 && j < j1) atomicAdd(&cnt[j - j0], 1); });
+    if (ovf) GN_SCAN_TABLE(ovf, (long long)lo, (long long)hi, tid, { (void)t; if (j >= j0 && j < j1) atomicAdd(&cnt[j - j0], 1); });
     __threadfence_block();
     __syncthreads();
-    // exclusive scan of cnt[0..n): thread t owns the contiguous piece [t*per, (t+1)*per)
-    const int per = (n + 255) / 256;
-    const int j0 = min(tid * per, n), j1 = min(j0 + per, n);
+    // exclusive scan of cnt[0..n): thread t owns the contiguous piece [t*pp, (t+1)*pp)
+    const int pp = (n + 255) / 256;
+    const int p0 = min(tid * pp, n), p1 = min(p0 + pp, n);
     int sum = 0;
-    for (int j = j0; j < j1; ++j) sum += cnt[j];
+    for (int j = p0; j < p1; ++j) sum += cnt[j];
     chunk_sum[tid] = sum;
     __syncthreads();
     if (tid == 0) { int run = 0; for (int t = 0; t < 256; ++t) { const int v = chunk_sum[t]; chunk_sum[t] = run; run += v; } }
     __syncthreads();
     int run = chunk_sum[tid];
-    for (int j = j0; j < j1; ++j) {
+    for (int j = p0; j < p1; ++j) {
         const int d = cnt[j];
         cnt[j] = run;                                            // becomes the fill cursor of source j
-        rev_ptr[lo + j] = base + run;
-        if (d > REV_SORT_MIN && d <= REV_SORT_CAP) hubs[atomicAdd(nhubs, 1)] = lo + j;
+        rev_ptr[j0 + j] = base + run;
+        if (d > REV_SORT_MIN && d <= REV_SORT_CAP) hubs[atomicAdd(nhubs, 1)] = j0 + j;
         run += d;
     }
     __threadfence_block();
     __syncthreads();
-    for (long long t = (long long)lo * K + tid; t < (long long)hi * K; t += 256) {
-        const int j = nbr[t];
-        if (j >= 0) {
-            const int i = (int)(t / K), sl = (int)(t % K);
-            rev_rows[base + atomicAdd(&cnt[j - lo], 1)] = i * S + sl;
+    GN_SCAN_TABLE(nbr, (long long)lo * K, (long long)hi * K, tid, {
+        if (j >= j0 && j < j1) {
+            const int i = (int)(t / K), sk = (int)(t % K);
+            rev_rows[base + atomicAdd(&cnt[j - j0], 1)] = i * S + sk;
         }
-    }
-    if (ovf)
-        for (int i = lo + tid; i < hi; i += 256) {
-            const int j = ovf[i];
-            if (j >= 0) rev_rows[base + atomicAdd(&cnt[j - lo], 1)] = N * S + ovf_pos[i];
-        }
+    });
+    if (ovf) GN_SCAN_TABLE(ovf, (long long)lo, (long long)hi, tid, {
+        if (j >= j0 && j < j1) rev_rows[base + atomicAdd(&cnt[j - j0], 1)] = N * S + ovf_pos[t];
+    });
 }
 
-// ev: >= 2*(B+1) ints of workspace (edges per event, their exclusive scan); scratch: [N] ints (events above
-// REV_EV_CAP pulses); hubs: [N] ints, nhubs: [1] (the hub list for gn_edgeconv_dq_gather); tmp: scan workspace
+// Slices per event: enough workgroups to fill the chip, at most 64 (redundant table reads grow with it)
+int rev_event_slices(int B) {
+    int nsl = (1024 + (B > 0 ? B : 1) - 1) / (B > 0 ? B : 1);
+    return nsl < 1 ? 1 : (nsl > 64 ? 64 : nsl);
+}
+// ev: >= 2*(B*NSL+1) ints of workspace (edges per (event, slice), their exclusive scan), NSL = rev_event_slices(B);
+// scratch: [N] ints (slices above REV_EV_CAP sources); hubs: [N] ints, nhubs: [1] (the hub list for
+// gn_edgeconv_dq_gather); tmp: scan workspace for B*NSL entries
 hipError_t launch_rev_build_events(const int* nbr, int N, int K, int S, const int* ovf, const int* ovf_pos, const int* ptr,
                                    int B, int* rev_ptr, int* rev_rows, int* ev, int* scratch, int* hubs, int* nhubs,
                                    int* tmp, hipStream_t st) {
     if (N == 0 || B == 0) return hipSuccess;
     if ((long long)N * S + N >= (1ll << 31)) return hipErrorInvalidValue;
+    const int NSL = rev_event_slices(B);
+    const int G = B * NSL;
     int* ev_edges = ev;
-    int* ev_base = ev + (B + 1);
-    hipLaunchKernelGGL(rev_event_count, dim3(B), dim3(256), 0, st, nbr, ovf, ptr, K, ev_edges, nhubs);
-    hipError_t e = launch_scan(ev_edges, ev_base, B, tmp, ev_base + B, st);
+    int* ev_base = ev + (G + 1);
+    hipLaunchKernelGGL(rev_event_count, dim3(G), dim3(256), 0, st, nbr, ovf, ptr, K, NSL, ev_edges, nhubs);
+    hipError_t e = launch_scan(ev_edges, ev_base, G, tmp, ev_base + G, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rev_event_build, dim3(B), dim3(256), 0, st, nbr, ovf, ovf_pos, ptr, ev_base, B, N, K, S, rev_ptr,
+    hipLaunchKernelGGL(rev_event_build, dim3(G), dim3(256), 0, st, nbr, ovf, ovf_pos, ptr, ev_base, B, N, K, S, NSL, rev_ptr,
                        rev_rows, scratch, hubs, nhubs);
     hipLaunchKernelGGL(rev_sort_kernel, dim3(N < 1024 ? N : 1024), dim3(256), 0, st, rev_ptr, hubs, nhubs, rev_rows);
     return hipGetLastError();

@@ -10,6 +10,7 @@ hipError_t launch_knn(const float* x, long long ldx, const int* cols, int D, con
 hipError_t launch_scan(const int* in, int* out, int n, int* tmp, int* total, hipStream_t st);
 hipError_t launch_ovf_compact(const int* ovf, int N, int* flag_pos, int* tmp, int* ovf_centre, int* ovf_src,
                               int* ovf_cnt, hipStream_t st);
+int rev_event_slices(int B);
 hipError_t launch_rev_build_events(const int* nbr, int N, int K, int S, const int* ovf, const int* ovf_pos, const int* ptr,
                                    int B, int* rev_ptr, int* rev_rows, int* ev, int* scratch, int* hubs, int* nhubs,
                                    int* tmp, hipStream_t st);

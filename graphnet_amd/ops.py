@@ -135,16 +135,16 @@ class NeighbourTable:
         ev_ptr = getattr(self, "event_ptr", None)
         B = int(ev_ptr.shape[0]) - 1 if ev_ptr is not None else 0
         # edges never leave an event (built by knn_graph): per-event build with LDS counters, one workgroup per
-        # event - only when there are enough events to fill the chip (a handful of 10^4-pulse events, BASELINE
-        # configs[4], would run on a handful of CUs: 5.4 ms instead of 0.4 ms for the global build)
-        if ev_ptr is not None and (self.ovf is None or getattr(self, "ovf_pos", None) is not None) \
-                and B >= 64 and N <= 2048 * B:
+        # (event, slice of its sources) - a handful of 10^4-pulse events (BASELINE configs[4]) is cut into enough
+        # slices to fill the chip
+        if ev_ptr is not None and (self.ovf is None or getattr(self, "ovf_pos", None) is not None) and B >= 1:
+            G = B * int(L.gn_rev_event_slices(B))
             rev_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
             rev_rows = torch.empty(max(N * self.K + N, 1), dtype=torch.int32, device=dev)
-            ev = torch.empty(2 * (B + 1), dtype=torch.int32, device=dev)
+            ev = torch.empty(2 * (G + 1), dtype=torch.int32, device=dev)
             scratch = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
             hubs = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
-            tmp = torch.empty(int(L.gn_scan_tmp_ints(max(B, 1))) + 1, dtype=torch.int32, device=dev)
+            tmp = torch.empty(int(L.gn_scan_tmp_ints(max(G, 1))) + 1, dtype=torch.int32, device=dev)
             nhubs = tmp[-1:]
             with _timed("rev_build"):
                 _lib.check(L.gn_rev_build_events(_p(self.nbr), N, self.K, _p(self.ovf), _p(getattr(self, "ovf_pos", None)),

@@ -71,6 +71,9 @@ int gn_rev_build(const int32_t* nbr, int32_t N, int32_t K, const int32_t* ovf_sr
  * array gn_knn_graph wrote) or NULL; ovf_pos[i]: index of centre i's overflow row (the exclusive scan gn_ovf_compact
  * leaves in its `work` array); ev: 2*(B+1) ints and scratch: N ints of workspace; hubs [N] / nhubs [1]: the hub list
  * for gn_edgeconv_dq_gather; tmp: gn_scan_tmp_ints(B) ints. */
+/* An event's sources are cut into G = gn_rev_event_slices(B) slices, one workgroup each (a few huge events still
+ * fill the chip): ev then holds 2*(B*G+1) ints and tmp gn_scan_tmp_ints(B*G) ints. */
+int32_t gn_rev_event_slices(int32_t B);
 int gn_rev_build_events(const int32_t* nbr, int32_t N, int32_t K, const int32_t* ovf, const int32_t* ovf_pos,
                         const int32_t* ptr, int32_t B, int32_t* rev_ptr, int32_t* rev_rows, int32_t* ev,
                         int32_t* scratch, int32_t* hubs, int32_t* nhubs, int32_t* tmp, void* stream);
