@@ -35,4 +35,21 @@ print(f"config5 B={B} N={b.x.shape[0]} k=16 {dtype}: {1e3*dt:.1f} ms/step  {B/dt
 ops.enable_timers(True)                 # per-op HIP events (adds host work: not part of the timed steps above)
 for _ in range(3): step()
 torch.cuda.synchronize()
-print({k: round(ms / 3, 3) for k, (n, ms) in ops.timer_summary().items()})
+summary = ops.timer_summary()
+print({k: round(ms / 3, 3) for k, (n, ms) in summary.items()})
+# bench-style JSON line (BASELINE configs[4] has no bench.py leg).  Roofline of the kernel family this config stresses:
+# the brute-force k-NN ("LDS/VALU-bound; report pairs/s"), 4 graphs of sum(n_i^2) pair distances per step,
+# each pair = 8 fp32 operations (3 sub, 3 mul, 2 add) -> against the fp32 vector peak of 157.3 TFLOP/s
+import json
+n = b.n_pulses.double()
+pairs = 4.0 * float((n * n).sum())
+t_knn = summary.get("knn_graph", (0, 0.0))[1] / 3 * 1e-3
+print(json.dumps({
+    "metric": "events/sec DynEdge fwd+bwd+Adam, ~1e4 pulses/event, k=16", "value": B / dt, "unit": "events/s",
+    "n_gpus": 1, "steps": steps, "ms_per_step": 1e3 * dt, "dtype": dtype, "data": "synthetic",
+    "config": {"workload": "configs[4]: high-energy tracks, ~1e4 pulses/event, k=16, 4 DynEdgeConv layers (default sizes)",
+               "events_per_gpu": B, "pulses_per_gpu": int(b.x.shape[0]), "pair_distances_per_step": pairs},
+    "roofline": {"bound": "valu", "kernel": "knn_kernel<17,3,*> (4 graphs per step)", "achieved": 8.0 * pairs / max(t_knn, 1e-9) / 1e12,
+                 "peak": 157.3, "unit": "TFLOP/s (fp32 vector)", "frac": 8.0 * pairs / max(t_knn, 1e-9) / 1e12 / 157.3,
+                 "pairs_per_s": pairs / max(t_knn, 1e-9), "launch_ms": 1e3 * t_knn / 4, "traffic": None},
+    "phase_ms_per_step": {k: ms / 3 for k, (n_, ms) in sorted(summary.items(), key=lambda kv: -kv[1][1])}}))
