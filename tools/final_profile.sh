@@ -1,14 +1,31 @@
 #!/bin/bash
-# Round artefacts on the GPU box: bench line, rocprofv3 kernel trace of the same command, HBM traffic (two --pmc passes).
-# usage: tools/final_profile.sh <tag>     (writes gpurun_out/<tag>_*)
+# Round artefacts on the GPU box: bench line, rocprofv3 kernel trace of the same command, HBM traffic (two --pmc passes),
+# SQ utilisation counters of the edge kernels, kernel traces of the configs[3] / configs[4] runners.
+# usage: GN_COMMIT=<short sha> tools/final_profile.sh <tag>     (writes gpurun_out/<tag>_*)
 tag=$1
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
+echo "bench done"
 rm -rf gpurun_out/prof_$tag; mkdir -p gpurun_out/prof_$tag
-rocprofv3 --kernel-trace -d gpurun_out/prof_$tag/kt -o kt -- python3 bench.py --no-cpu-baseline --extra-events 0 > gpurun_out/prof_$tag/kt.log 2>&1 || exit 2
+rocprofv3 --kernel-trace -d gpurun_out/prof_$tag/kt -o kt -- python3 bench.py --no-cpu-baseline --extra-events 0 --fp32-events 0 > gpurun_out/prof_$tag/kt.log 2>&1 || exit 2
 python3 tools/rocpd_stats.py $(find gpurun_out/prof_$tag/kt -name "*.db" | head -1) gpurun_out/${tag}_bench_kernel_stats.csv > /dev/null
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/prof_$tag/f -o f -- python3 bench.py --no-cpu-baseline --steps 5 --extra-events 0 > gpurun_out/prof_$tag/f.log 2>&1 || exit 3
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/prof_$tag/w -o w -- python3 bench.py --no-cpu-baseline --steps 5 --extra-events 0 > gpurun_out/prof_$tag/w.log 2>&1 || exit 4
+echo "kernel trace done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/prof_$tag/f -o f -- python3 bench.py --no-cpu-baseline --steps 5 --extra-events 0 --fp32-events 0 > gpurun_out/prof_$tag/f.log 2>&1 || exit 3
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/prof_$tag/w -o w -- python3 bench.py --no-cpu-baseline --steps 5 --extra-events 0 --fp32-events 0 > gpurun_out/prof_$tag/w.log 2>&1 || exit 4
 python3 tools/traffic_from_pmc.py $(find gpurun_out/prof_$tag/f -name "*.db" | head -1) $(find gpurun_out/prof_$tag/w -name "*.db" | head -1) gpurun_out/${tag}_traffic.json 4096
+echo "traffic done"
+P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
+P2="SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD"
+rocprofv3 --kernel-trace --pmc $P1 -d gpurun_out/prof_$tag/a -o a -- python3 tools/prof_edge.py all 4096 3 > gpurun_out/prof_$tag/a.log 2>&1 || exit 5
+rocprofv3 --kernel-trace --pmc $P2 -d gpurun_out/prof_$tag/b -o b -- python3 tools/prof_edge.py all 4096 3 > gpurun_out/prof_$tag/b.log 2>&1 || exit 6
+{ echo "# rocprofv3 --kernel-trace --pmc <8 counters per pass> -- python3 tools/prof_edge.py all 4096 3 (B=4096: 623k pulses, 4.98M edges); per-kernel averages per launch";
+  echo "# pass A: $P1"; python3 tools/pmc_summary.py $(find gpurun_out/prof_$tag/a -name "*.db" | head -1) edge_;
+  echo "# pass B: $P2"; python3 tools/pmc_summary.py $(find gpurun_out/prof_$tag/b -name "*.db" | head -1) edge_; } > gpurun_out/${tag}_pmc_edge_util.txt 2>&1
+echo "pmc util done"
+rocprofv3 --kernel-trace -d gpurun_out/prof_$tag/c4 -o c4 -- python3 tools/run_config4.py 256 bf16 5 > gpurun_out/${tag}_config4_b256.log 2>&1 || exit 7
+python3 tools/rocpd_stats.py $(find gpurun_out/prof_$tag/c4 -name "*.db" | head -1) gpurun_out/${tag}_config4_kernel_stats.csv > /dev/null
+rocprofv3 --kernel-trace -d gpurun_out/prof_$tag/c5 -o c5 -- python3 tools/run_config5.py 16 bf16 5 > gpurun_out/${tag}_config5_b16.log 2>&1 || exit 8
+python3 tools/rocpd_stats.py $(find gpurun_out/prof_$tag/c5 -name "*.db" | head -1) gpurun_out/${tag}_config5_kernel_stats.csv > /dev/null
 find gpurun_out/prof_$tag -name "*.db" -delete
+echo "all done"

@@ -31,5 +31,12 @@ for grp, sub in GROUPS.items():
                 "events_per_gpu": EVENTS,
                 "note": "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads), WRITE_SIZE as is; "
                         f"separate --pmc passes over bench.py, B={EVENTS}"}
+import subprocess
+try:
+    out["_commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True,
+                                    cwd=__import__("os").path.dirname(__import__("os").path.abspath(__file__))).stdout.strip() or \
+        __import__("os").environ.get("GN_COMMIT", "unknown")
+except Exception:
+    out["_commit"] = __import__("os").environ.get("GN_COMMIT", "unknown")
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: round(v["bytes_per_launch"] / 1e6, 1) for k, v in out.items()}), "MB per launch")
+print(json.dumps({k: round(v["bytes_per_launch"] / 1e6, 1) for k, v in out.items() if isinstance(v, dict)}), "MB per launch")
