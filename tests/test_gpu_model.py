@@ -385,3 +385,28 @@ def test_fit_loop_on_the_hip_backbone(tmp_path):
     assert m.best_model_path is not None and "DynEdge-epoch=" in m.best_model_path
     preds = m.predict(val)
     assert preds[0].shape == (16, 1) and bool(torch.isfinite(preds[0]).all())
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """configs[2] control flow on real HIP tensors: ``python bench.py --gpus 2`` starts two ranks itself; with
+    ``GN_BENCH_REHEARSE=1`` both use cuda:0 and exchange gradients over gloo (a one-GPU box has no second device for
+    RCCL).  The line must say two ranks, identical weights on both after the timed steps, and a non-zero exchange."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["GN_BENCH_REHEARSE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--events", "128", "--steps", "3",
+                        "--warmup", "1", "--extra-events", "0", "--fp32-events", "0", "--profile-steps", "2"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["backend"] == "gloo" and out["scaling"] == "weak"
+    assert out["weights_identical_across_ranks"] is True
+    assert out["allreduce_us_per_step"] > 0 and out["allreduce_bytes"] == 4 * 1382321
+    assert out["config"]["global_batch"] == 256 and out["value"] > 0
+    assert "cpu_baseline" not in out                       # rank 0 times the CPU leg at N = 1 only
