@@ -54,7 +54,7 @@ def _cmp_table(table, nbr_oracle, k):
 
 # ------------------------------------------------------------------------------ k-NN
 @pytest.mark.parametrize("mode", ["compat", "strict"])
-@pytest.mark.parametrize("k", [8, 16, 3])
+@pytest.mark.parametrize("k", [8, 16, 3, 24])
 def test_knn_bit_exact_synthetic(oracle, mode, k):
     from graphnet_amd import ops
     b = _batch(40, seed=11)
