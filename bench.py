@@ -581,24 +581,29 @@ def main():
             "colsum": sum(N * 4 * h1 for _, h1, _ in conv) + N * 4 * (336 + 256),
             "segment_pool_fwd": N * 256 * 4, "segment_pool_bwd": N * 256 * (4 + act),
         }
-        dom = max(timers.items(), key=lambda kv: kv[1][1]) if timers else ("none", (1, 0.0))
-        name, (launches, ms) = dom
+        # candidates: ONE kernel shape each (the op groups that mix shapes list them in `detail`: conv 1 is 128 wide,
+        # conv 2-4 are 336 wide; the GEMM groups hold five different contractions) - this is the duration a rocprofv3
+        # kernel trace reports for that kernel
+        cands = {}
+        for gname, tv in timers.items():
+            shapes = {k: v for k, v in detail.items() if k.startswith(gname + "[")}
+            if shapes:
+                cands.update({k: (gname, v) for k, v in shapes.items()})
+            else:
+                cands[gname] = (gname, tv)
+        kernel_shape, (name, (launches, ms)) = (max(cands.items(), key=lambda kv: kv[1][1][1]) if cands
+                                                else ("none", ("none", (1, 0.0))))
         per_launch_ms = ms / max(launches, 1)
         lps = launches / prof_steps
-        kernel_shape = None
         if name in flops:
             bound, unit = "mfma", "TFLOP/s"
-            # the group mixes layer shapes (conv 1 is 128 wide, conv 2-4 are 336 wide): price the ONE kernel shape
-            # that takes the most time with its own contraction, launch by launch - this is the duration a
-            # rocprofv3 kernel trace reports for that kernel
-            shapes = {k: v for k, v in detail.items() if k.startswith(name + "[")}
-            if shapes:
-                kernel_shape, (launches, ms) = max(shapes.items(), key=lambda kv: kv[1][1])
-                h1p, h2 = (int(v) for v in kernel_shape[len(name) + 1:-1].split("x"))
-                h1 = next(h for _, h, _ in conv if (h + 31) // 32 * 32 == h1p)
-                per_launch_ms = ms / max(launches, 1)
-                lps = launches / prof_steps
-                achieved = 2 * E * h1 * h2 / (per_launch_ms * 1e-3) / 1e12
+            if "[" in kernel_shape:
+                a_, b_ = (int(v) for v in kernel_shape[len(name) + 1:-1].split("x"))
+                if name.startswith("edgeconv"):        # [H1p x H2]: contraction over the edge rows
+                    h1 = next(h for _, h, _ in conv if (h + 31) // 32 * 32 == a_)
+                    achieved = 2 * E * h1 * b_ / (per_launch_ms * 1e-3) / 1e12
+                else:                                  # [K x N]: one GEMM over the N pulse rows
+                    achieved = 2 * N * a_ * b_ / (per_launch_ms * 1e-3) / 1e12
             else:
                 achieved = flops[name] / lps / (per_launch_ms * 1e-3) / 1e12
         else:
@@ -633,7 +638,7 @@ def main():
             "allreduce_alone_us": ar_alone_us,
             "allreduce_bytes": int(sync.flat.numel()) * 4,
             "weights_identical_across_ranks": same_weights,
-            "roofline": {"bound": bound, "kernel": kernel_shape or name, "achieved": achieved, "peak": peak, "unit": unit,
+            "roofline": {"bound": bound, "kernel": kernel_shape, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
                          "launch_ms": per_launch_ms, "launches_per_step": lps},
             "group_tflops": {k: flops[k] / (timers[k][1] / prof_steps * 1e-3) / 1e12 for k in flops if k in timers},

@@ -192,7 +192,7 @@ struct EdgeGraph {
 // Layout of the opaque "saved for backward" buffer of one EdgeConv layer (bytes):
 //   words : uint32 [(N*S + N)][ceil(H2/32)]  relu bits, row-major   (generic kernels; overflow rows)
 //   maskB : uint8 / uint16 [N][H2]           slot masks, S = 8 / 16 bits (persistent v2 kernels)
-//   hbits : uint8  [N*S][H1p/8] (+16 slack)  h > 0 bits              (persistent v2 kernels)
+//   hbits : uint8  [N*S + 128][H1p/8] (+16)  h > 0 bits; 128 slack rows  (persistent v2 kernels)
 struct SavedLayout { long long off_words, off_maskB, off_hbits, total; };
 inline SavedLayout saved_layout(long long N, int S, int H1p, int H2) {
     auto up = [](long long v) { return (v + 255) / 256 * 256; };
@@ -200,7 +200,7 @@ inline SavedLayout saved_layout(long long N, int S, int H1p, int H2) {
     L.off_words = 0;
     L.off_maskB = up((N * S + N) * ((H2 + 31) / 32) * 4);
     L.off_hbits = L.off_maskB + up(N * H2 * (S > 8 ? 2 : 1));
-    L.total = L.off_hbits + up(N * S * (H1p / 8) + 16);
+    L.total = L.off_hbits + up((N * S + 128) * (H1p / 8) + 16);    // two tiles of slack rows: branch-free look-ahead stores
     return L;
 }
 

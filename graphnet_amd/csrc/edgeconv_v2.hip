@@ -951,6 +951,331 @@ __global__ __launch_bounds__(V2_THREADS, 2) void edge_dw2_v2_kernel(
     }
 }
 
+// =============================================================================== dW2 / db2 / hbits, software-pipelined
+// Same contraction and outputs as edge_dw2_v2_kernel; what changes is WHEN things are issued and how many waves share a
+// SIMD.  In the kernel above the two waves of a SIMD meet at the tile barrier and then run the same program: both issue
+// their MFMAs (with a wait on LDS at every k-step), then both run ~150 vector instructions with the matrix pipe idle
+// (s_memtime probe: 3.4k cycles per tile against 1.5k of MFMA and 1.5k of vector issue per SIMD - they do not overlap
+// ACROSS waves: an MFMA that waits for the pipe holds the SIMD's vector issue, so only a wave's OWN vector instructions
+// ride in the shadow of its MFMAs).  Here every iteration is ONE straight-line block:
+//   * iteration T multiplies tile T (h in LDS, dm^T fragments ready in registers) and meanwhile
+//       - builds h of tile T+1 from chunks gathered during iteration T-1 and re-issues each chunk's loads for tile T+2
+//         as soon as its registers are free (a full iteration of latency cover with one register set),
+//       - builds the dm^T fragments of tile T+1 from g_out / slot bytes loaded during iteration T-1, loads those of T+2,
+//       - reads the h^T fragment of a later MFMA while the current one runs (rolling window, counted waits);
+//   * NW = 4 waves (ONE per SIMD, 512 registers): a wave owns NA = 2 column blocks of dm, so an h^T fragment read from
+//     LDS feeds two MFMAs and the wave has 2 x NBLK independent accumulators; NW = 8: the blocking of the kernel above;
+//   * no branch in the loop: look-ahead tiles past the end are clamped (loads) or land in slack rows (hbits stores,
+//     saved_layout() keeps two tiles of slack), invalid centres of the last tile are cut by one byte mask per tile;
+//   * the k1 block count of the workgroup is a template parameter (the half is chosen once, at kernel entry);
+//   * db2 = column sums of dm: when the h tile has a whole 8-column pad chunk (ceil(H1/8)*8 < H1p) its first column is
+//     set to 1.0 once and the MFMAs deliver db2 as that column of dW2 (BSUM = false); otherwise 3 instructions per
+//     k-step as before (BSUM = true).
+// What did NOT help (B = 4096, ms per launch, this kernel 1.25): sched_group_barrier patterns "1 MFMA, 2 LDS reads, n
+// vector instructions" (1.5-2.3: the pass also displaces the look-ahead loads), fenced matrix / vector sections with the
+// SIMD partners in opposite phases (1.34), one scheduling region per k-step (1.25), s_setprio 1 for waves 4-7 (1.25),
+// NW = 4 (1.58: one wave's stream alone does not keep both pipes busy as the compiler orders it).
+template <int NB1, int NBH, int S, int V, int NBLK, bool BSUM, int NW>
+__device__ __forceinline__ void edge_dw2_v3_body(
+    const EdgeGraph& g, const unsigned char* __restrict__ PQb, const int H1, const int H2,
+    const unsigned char* __restrict__ goutb, const unsigned int ldg2, const unsigned char* __restrict__ maskB,
+    unsigned char* __restrict__ hbits, float* __restrict__ slab, float* __restrict__ db2_part, const int ntiles,
+    const int part, const int nparts, const int kb0, unsigned char* __restrict__ Hs, const unsigned char* __restrict__ MaskLut)
+{
+    static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
+    constexpr int NT = NW * 64;                     // threads
+    constexpr int TPR = NT / V2_ROWS;               // threads per h row
+    constexpr int NA = 8 / NW;                      // dm column blocks per wave
+    constexpr int K = NB1 * 32;
+    constexpr int CHUNKS = K / 8;
+    constexpr int NI = (NBLK * 4 + TPR - 1) / TPR;  // 16-byte chunks per thread
+    constexpr int HP = tr_pitch(NBH * 64);
+    constexpr int BUFSZ = V2_ROWS * HP;
+    constexpr int CPT = V2_ROWS / S;                // centres per tile
+    constexpr unsigned int ROWPQ = 2u * K * 2u;     // bytes per P|Q row
+    constexpr int NQ = 4 * NBLK;                    // h^T fragments per tile and wave (each feeds NA MFMAs)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int kslots = g.K;
+    const int n2 = wave * (32 * NA) + r;            // first dm column of this lane (A rows): n2 + 32 a, a < NA; H2 == 256
+    const int cbeg = kb0 * 4;
+    const int cend_all = (kb0 + NBLK) * 4;
+    const int creal = (H1 + 7) / 8;
+    const int cend = cend_all < creal ? cend_all : creal;
+
+    f32x16 acc[NA][NBLK];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) zero_acc(acc[a][nb]);
+    float bsum[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) bsum[a] = 0.0f;
+
+    // ---- per-thread constants of the h build (TPR threads per row)
+    const int grow = tid / TPR, gc0 = tid % TPR;
+    const int sl = grow % S, slc = sl < kslots ? sl : 0;
+    unsigned int c16[NI], ldsw[NI], cix[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = cbeg + gc0 + TPR * i;
+        const int cc = c < cend ? c : cend - 1;
+        cix[i] = (unsigned int)cc;
+        c16[i] = (unsigned int)cc * 16u;
+        ldsw[i] = (unsigned int)(grow * HP + (cc - cbeg) * 16);
+    }
+    // pad columns of the window: zero once in both buffers; the first column of chunk `creal` (if in this window) is 1.0
+    for (int idx = tid; idx < 2 * V2_ROWS * (cend_all - cend); idx += NT) {
+        const int bufz = idx / (V2_ROWS * (cend_all - cend)), rem = idx % (V2_ROWS * (cend_all - cend));
+        const int rowz = rem / (cend_all - cend), cz = cend + rem % (cend_all - cend);
+        u32x4 z = {0u, 0u, 0u, 0u};
+        if (!BSUM && cz == creal) z[0] = 0x00003f80u;
+        *reinterpret_cast<u32x4*>(&Hs[bufz * BUFSZ + rowz * HP + (cz - cbeg) * 16]) = z;
+    }
+
+    const int per = (ntiles + nparts - 1) / nparts;
+    int tile = part * per;
+    const int tile_end = min(ntiles, tile + per);
+    const unsigned int Nm1 = (unsigned int)(g.N - 1);
+
+    // centre of this thread's build row in tile t, clamped to a real node (look-ahead tiles, last tile)
+    auto build_centre = [&](int t) -> unsigned int {
+        const unsigned int c = (unsigned int)(t * CPT + grow / S);
+        return c < Nm1 ? c : Nm1;
+    };
+    auto nbr_of = [&](unsigned int c) -> int { return g.nbr[__umul24(c, (unsigned int)kslots) + (unsigned int)slc]; };
+    u32x4 preg[NI], qreg[NI];
+    auto gather_chunk = [&](int i, unsigned int po, unsigned int qo) {
+        preg[i] = *reinterpret_cast<const u32x4*>(PQb + (po + c16[i]));
+        qreg[i] = *reinterpret_cast<const u32x4*>(PQb + (qo + c16[i]));
+    };
+    auto row_offsets = [&](unsigned int c, int raw, unsigned int& po, unsigned int& qo) {
+        const unsigned int js = (unsigned int)(raw < 0 ? 0 : raw);
+        po = __umul24(c, ROWPQ);
+        qo = __umul24(js, ROWPQ) + 2u * K;
+    };
+    // A side of tile t: g_out bits (bf16 in the low half) and the four slot bytes of this lane and column, packed.  The
+    // tile part of every address is uniform (scalar unit); per lane: one add + one clamp for g_out (a look-ahead tile or
+    // the last tile may name centres >= N; their slot bytes are cut by valid_bytes(), the mask rows read there are slack
+    // of `saved`)
+    const unsigned int gmax = Nm1 * ldg2 + (unsigned int)n2 * 2u;
+    const unsigned int lane_goff = (S == 8 ? (unsigned int)h * ldg2 : 0u) + (unsigned int)n2 * 2u;
+    const unsigned int lane_moff = S == 8 ? (unsigned int)(h * H2 + n2) : (unsigned int)(n2 * 2 + h);
+    auto load_a = [&](int t, unsigned int (&gv)[NA][4], unsigned int (&mv)[NA]) {
+        const int tc = t < ntiles ? t : ntiles - 1;                      // uniform
+#pragma unroll
+        for (int a = 0; a < NA; ++a) mv[a] = 0u;
+#pragma unroll
+        for (int s = 3; s >= 0; --s) {
+            const unsigned int cs = (unsigned int)(tc * CPT + (S == 8 ? 2 * s : s));     // uniform
+            unsigned int go = cs * ldg2 + lane_goff;
+            go = go < gmax ? go : gmax;
+            const unsigned int mo = cs * (unsigned int)(S == 8 ? H2 : 2 * H2) + lane_moff;    // uniform product + lane
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                gv[a][s] = (unsigned int)*reinterpret_cast<const unsigned short*>(goutb + go + 64u * a);
+                mv[a] = (mv[a] << 8) | (unsigned int)maskB[mo + (S == 8 ? 32u : 64u) * a];
+            }
+        }
+    };
+    // byte mask of the k-steps whose centre exists (tile t; all ones except in the last tile and beyond)
+    auto valid_bytes = [&](int t, bool mine) -> unsigned int {
+        const int nv = mine ? g.N - t * CPT : 0;                         // uniform
+        int ns0, ns1;
+        if (S == 8) { ns0 = (nv + 1) >> 1; ns1 = nv >> 1; } else { ns0 = nv; ns1 = nv; }
+        ns0 = ns0 < 0 ? 0 : (ns0 > 4 ? 4 : ns0);
+        ns1 = ns1 < 0 ? 0 : (ns1 > 4 ? 4 : ns1);
+        const unsigned int b0 = ns0 >= 4 ? 0xffffffffu : ((1u << (8 * ns0)) - 1u);
+        const unsigned int b1 = ns1 >= 4 ? 0xffffffffu : ((1u << (8 * ns1)) - 1u);
+        return h ? b1 : b0;
+    };
+    auto make_afrag = [&](unsigned int gbits, unsigned int m) -> bf16x8 {
+        const unsigned int gbf = gbits | (gbits << 16);
+        const u32x4 mk = *reinterpret_cast<const u32x4*>(&MaskLut[m * 16]);
+        const u32x4 gb4 = {gbf, gbf, gbf, gbf};
+        const u32x4 aw = gb4 & mk;
+        return __builtin_bit_cast(bf16x8, aw);
+    };
+
+    if (tile < tile_end) {
+        // ---------------- prologue: h(tile) in buffer 0, chunks of tile+1 in flight, fragments of tile ready
+        bf16x8 afrag[NA][4];
+        unsigned int gb1[NA][4], mw1[NA];
+        unsigned int c2;            // centre / neighbour of this thread's build row in tile+2
+        int raw2;
+        {
+            const unsigned int c0 = build_centre(tile), c1 = build_centre(tile + 1);
+            const int raw0 = nbr_of(c0), raw1 = nbr_of(c1);
+            c2 = build_centre(tile + 2);
+            raw2 = nbr_of(c2);
+            unsigned int ga0[NA][4], mw0[NA];
+            load_a(tile, ga0, mw0);
+            load_a(tile + 1, gb1, mw1);
+            unsigned int po, qo;
+            row_offsets(c0, raw0, po, qo);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) gather_chunk(i, po, qo);
+            const unsigned int hrow = (unsigned int)(tile * V2_ROWS + grow) * (unsigned int)CHUNKS;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const u32x4 hv = act_sum_bf16x8<V>(preg[i], qreg[i]);
+                *reinterpret_cast<u32x4*>(&Hs[ldsw[i]]) = hv;
+                hbits[hrow + cix[i]] = (unsigned char)(V == 0 ? nonzero_bits_bf16x8(hv) : positive_bits_bf16x8(hv));
+            }
+            row_offsets(c1, raw1, po, qo);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) gather_chunk(i, po, qo);
+            const unsigned int vb = valid_bytes(tile, true);
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                mw0[a] &= vb;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const unsigned int m = (mw0[a] >> (8 * s)) & 0xffu;
+                    if (BSUM) bsum[a] += __builtin_bit_cast(float, ga0[a][s] << 16) * (float)__builtin_popcount(m);
+                    afrag[a][s] = make_afrag(ga0[a][s], m);
+                }
+            }
+        }
+        __syncthreads();
+
+        const int g4 = lane >> 4, li = lane & 15;
+        const unsigned int tr_base = (unsigned int)((8 * (g4 >> 1) + (li >> 2)) * HP + (16 * (g4 & 1) + 4 * (li & 3)) * 2);
+        unsigned int hrow1 = (unsigned int)((tile + 1) * V2_ROWS + grow) * (unsigned int)CHUNKS;   // hbits row offset of tile+1
+
+        int buf = 0;
+        for (; tile < tile_end; ++tile, buf ^= 1) {
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            // look-ahead loads: neighbour of tile+3, A side of tile+2
+            const unsigned int c3 = build_centre(tile + 3);
+            const int raw3 = nbr_of(c3);
+            unsigned int gb2[NA][4], mw2[NA];
+            load_a(tile + 2, gb2, mw2);
+            unsigned int po2, qo2;
+            row_offsets(c2, raw2, po2, qo2);
+            const unsigned char* hb = Hs + (buf ? BUFSZ : 0) + tr_base;
+            unsigned char* hw = Hs + (buf ? 0 : BUFSZ);
+            const unsigned int vb1 = valid_bytes(tile + 1, tile + 1 < tile_end);   // (tile_end is not this workgroup's: no db2 from it)
+#pragma unroll
+            for (int a = 0; a < NA; ++a) mw1[a] &= vb1;
+
+            constexpr int AHEAD = NW == 4 ? 3 : NBLK;       // fragments read ahead of the MFMAs that use them
+            bf16x8 bfr[NQ];
+            auto read_b = [&](int q) {
+                const int s = q / NBLK, nb = q % NBLK;
+                const unsigned char* p0 = hb + (16 * s) * HP + nb * 64;
+                const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+                const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * HP));
+                bfr[q] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+            };
+#pragma unroll
+            for (int q = 0; q < AHEAD; ++q) read_b(q);
+
+            bf16x8 anext[NA][4];
+            unsigned int hbv[NI];
+            constexpr int CSTEP = NQ / NI;                  // a chunk of h every CSTEP fragments
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int s = q / NBLK, nb = q % NBLK;
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+                    acc[a][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[a][s], bfr[q], acc[a][nb], 0, 0, 0);
+                if (q + AHEAD < NQ) read_b(q + AHEAD);
+                // vector work in the shadow of the MFMAs: the h chunks spread over the tile, fragment s at the end of k-step s
+                if (q % CSTEP == 0 && q / CSTEP < NI) {
+                    const int i = q / CSTEP;
+                    const u32x4 hv = act_sum_bf16x8<V>(preg[i], qreg[i]);
+                    *reinterpret_cast<u32x4*>(&hw[ldsw[i]]) = hv;
+                    hbv[i] = V == 0 ? nonzero_bits_bf16x8(hv) : positive_bits_bf16x8(hv);
+                    gather_chunk(i, po2, qo2);
+                }
+                if (nb == NBLK - 1) {
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        const unsigned int m = (mw1[a] >> (8 * s)) & 0xffu;
+                        if (BSUM) bsum[a] += __builtin_bit_cast(float, gb1[a][s] << 16) * (float)__builtin_popcount(m);
+                        anext[a][s] = make_afrag(gb1[a][s], m);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) hbits[hrow1 + cix[i]] = (unsigned char)hbv[i];
+            hrow1 += (unsigned int)(V2_ROWS * CHUNKS);
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { afrag[a][s] = anext[a][s]; gb1[a][s] = gb2[a][s]; }
+                mw1[a] = mw2[a];
+            }
+            c2 = c3; raw2 = raw3;
+            __syncthreads();
+        }
+    }
+
+    // ---- write this workgroup's part of slab `part`: dW2[H2][k1 window]; db2[H2] from the ones column or the sums
+    {
+        float* outp = slab + (long long)part * H2 * H1;
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) {
+            const int k1 = (kb0 + nb) * 32 + r;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                if (k1 < H1) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = wave * (32 * NA) + 32 * a + acc_row(q, h);
+                        outp[(long long)row * H1 + k1] = acc[a][nb][q];
+                    }
+                } else if (!BSUM && k1 == creal * 8) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        db2_part[(long long)part * H2 + wave * (32 * NA) + 32 * a + acc_row(q, h)] = acc[a][nb][q];
+                }
+            }
+        }
+        if (BSUM) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const float bs = bsum[a] + __shfl_xor(bsum[a], 32);
+                if (kb0 == 0 && h == 0) db2_part[(long long)part * H2 + n2 + 32 * a] = bs;
+            }
+        }
+    }
+}
+
+template <int NB1, int NBH, int HALVES, int S, int V, bool BSUM, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void edge_dw2_v3_kernel(
+    EdgeGraph g, const __bf16* __restrict__ PQ, int H1, int H2,
+    const __bf16* __restrict__ gout, long long ldg, const unsigned char* __restrict__ maskB,
+    unsigned char* __restrict__ hbits, float* __restrict__ slab, float* __restrict__ db2_part, int ntiles)
+{
+    static_assert(S == 8 || S == 16, "8 or 16 slots per centre");
+    constexpr int HP = tr_pitch(NBH * 64);
+    constexpr int NLAST = NB1 - (HALVES - 1) * NBH;                // k1 blocks of the last half
+    static_assert(NLAST > 0 && NLAST <= NBH, "halves");
+    __shared__ __attribute__((aligned(16))) unsigned char Hs[2 * V2_ROWS * HP];
+    __shared__ __attribute__((aligned(16))) unsigned char MaskLut[256 * 16];   // byte -> 8 x (0 / 0xFFFF) halfwords
+    for (int t = threadIdx.x; t < 256; t += NW * 64) {
+        u32x4 e;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            e[jj] = ((t >> (2 * jj)) & 1 ? 0x0000ffffu : 0u) | ((t >> (2 * jj + 1)) & 1 ? 0xffff0000u : 0u);
+        *reinterpret_cast<u32x4*>(&MaskLut[t * 16]) = e;
+    }
+    const int half = (int)blockIdx.x % HALVES, part = (int)blockIdx.x / HALVES;
+    const int nparts = ((int)gridDim.x + HALVES - 1) / HALVES;
+    const unsigned char* PQb = reinterpret_cast<const unsigned char*>(PQ);
+    const unsigned char* goutb = reinterpret_cast<const unsigned char*>(gout);
+    const unsigned int ldg2 = (unsigned int)ldg * 2u;
+    if (NLAST != NBH && half == HALVES - 1)
+        edge_dw2_v3_body<NB1, NBH, S, V, NLAST, BSUM, NW>(g, PQb, H1, H2, goutb, ldg2, maskB, hbits, slab, db2_part, ntiles,
+                                                               part, nparts, half * NBH, Hs, MaskLut);
+    else
+        edge_dw2_v3_body<NB1, NBH, S, V, NBH, BSUM, NW>(g, PQb, H1, H2, goutb, ldg2, maskB, hbits, slab, db2_part, ntiles,
+                                                             part, nparts, half * NBH, Hs, MaskLut);
+}
+
 // =============================================================================== backward (dh, dP, dpre)
 // One wave per 32-column block of dh: NB1 = 11 -> an 11-wave (704-thread) workgroup, 3 waves on
 // three SIMDs (VGPR budget 168): W2^T slice 64 + accumulators 32 + staging.  NB1 = 4 -> 8 waves.
@@ -1240,6 +1565,12 @@ hipError_t launch_edge_fwd_v2(const EdgeGraph& g, const void* PQ, int H1p, int H
     return hipGetLastError();
 }
 
+// GN_DW2_PIPELINED=0 selects the barrier-phased dW2 kernel (A/B measurements); default: the software-pipelined one
+static bool dw2_pipelined() {
+    static const bool on = [] { const char* e = getenv("GN_DW2_PIPELINED"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // number of slabs (= tile-range parts) the dW2 kernel writes for N nodes
 int edge_dw2_v2_parts(int N, int K, int H1p, int num_cus) {
     const long long ntiles = ((long long)N * edge_slots(K) + V2_ROWS - 1) / V2_ROWS;
@@ -1264,10 +1595,21 @@ hipError_t launch_edge_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, int H
 #define GN_DW2_LAUNCH(A, B, C, SS, GRID)                                                                    \
     hipLaunchKernelGGL((edge_dw2_v2_kernel<A, B, C, SS>), dim3(GRID), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ, \
                        H1, H2, (const __bf16*)gout, ldg, maskB, hbits, slab, db2_part, ntiles)
+#define GN_DW3_LAUNCH(A, B, C, SS, BS, GRID)                                                                \
+    hipLaunchKernelGGL((edge_dw2_v3_kernel<A, B, C, SS, 0, BS>), dim3(GRID), dim3(V2_THREADS), 0, st, g,           \
+                       (const __bf16*)PQ, H1, H2, (const __bf16*)gout, ldg, maskB, hbits, slab, db2_part, ntiles)
     const bool s8 = edge_slots(g.K) == 8;
-    if (H1p == 128) { if (s8) GN_DW2_LAUNCH(4, 4, 1, 8, parts); else GN_DW2_LAUNCH(4, 4, 1, 16, parts); }
-    else { if (s8) GN_DW2_LAUNCH(11, 6, 2, 8, parts * 2); else GN_DW2_LAUNCH(11, 6, 2, 16, parts * 2); }
+    if (dw2_pipelined()) {
+        const bool ones = (H1 + 7) / 8 * 8 < H1p;          // a whole pad chunk: db2 comes out of the MFMAs
+        if (H1p == 128) { if (s8) GN_DW3_LAUNCH(4, 4, 1, 8, true, parts); else GN_DW3_LAUNCH(4, 4, 1, 16, true, parts); }
+        else if (ones) { if (s8) GN_DW3_LAUNCH(11, 6, 2, 8, false, parts * 2); else GN_DW3_LAUNCH(11, 6, 2, 16, false, parts * 2); }
+        else { if (s8) GN_DW3_LAUNCH(11, 6, 2, 8, true, parts * 2); else GN_DW3_LAUNCH(11, 6, 2, 16, true, parts * 2); }
+    } else {
+        if (H1p == 128) { if (s8) GN_DW2_LAUNCH(4, 4, 1, 8, parts); else GN_DW2_LAUNCH(4, 4, 1, 16, parts); }
+        else { if (s8) GN_DW2_LAUNCH(11, 6, 2, 8, parts * 2); else GN_DW2_LAUNCH(11, 6, 2, 16, parts * 2); }
+    }
 #undef GN_DW2_LAUNCH
+#undef GN_DW3_LAUNCH
     return hipGetLastError();
 }
 
@@ -1320,12 +1662,16 @@ hipError_t launch_edge_max_dw2_v2(const EdgeGraph& g, const void* PQ, int H1p, i
         return hipErrorNotSupported;
     const int ntiles = v2_tiles(g);
     const int parts = edge_dw2_v2_parts(g.N, g.K, H1p, num_cus);
-    if (edge_slots(g.K) == 8)
-        hipLaunchKernelGGL((edge_dw2_v2_kernel<8, 4, 2, 8, 1>), dim3(parts * 2), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
-                           H1, H2, (const __bf16*)gout, ldg, maskB, hbits, slab, db2_part, ntiles);
-    else
-        hipLaunchKernelGGL((edge_dw2_v2_kernel<8, 4, 2, 16, 1>), dim3(parts * 2), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ,
-                           H1, H2, (const __bf16*)gout, ldg, maskB, hbits, slab, db2_part, ntiles);
+#define GN_DWM_LAUNCH(...)                                                                                  \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3(parts * 2), dim3(V2_THREADS), 0, st, g, (const __bf16*)PQ, H1, H2,     \
+                       (const __bf16*)gout, ldg, maskB, hbits, slab, db2_part, ntiles)
+    const bool s8 = edge_slots(g.K) == 8;
+    if (dw2_pipelined()) {      // H1 == H1p == 256: no pad chunk, db2 from the per-k-step sums
+        if (s8) GN_DWM_LAUNCH(edge_dw2_v3_kernel<8, 4, 2, 8, 1, true>); else GN_DWM_LAUNCH(edge_dw2_v3_kernel<8, 4, 2, 16, 1, true>);
+    } else {
+        if (s8) GN_DWM_LAUNCH(edge_dw2_v2_kernel<8, 4, 2, 8, 1>); else GN_DWM_LAUNCH(edge_dw2_v2_kernel<8, 4, 2, 16, 1>);
+    }
+#undef GN_DWM_LAUNCH
     return hipGetLastError();
 }
 hipError_t launch_edge_max_bwd_v2(const EdgeGraph& g, int H1p, int H2, const void* gout, long long ldg,

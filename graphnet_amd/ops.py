@@ -374,7 +374,7 @@ def linear_fwd(mode: int, segs: Sequence[Seg], Wp: Tensor, n_real: int, bias: Op
         out = torch.empty((M, cols), dtype=mode_dtype(mode) if out_lowp else torch.float32, device=Wp.device)
         if cols > n_real:
             out[:, n_real:].zero_()
-    with _timed("linear_fwd"):
+    with _timed("linear_fwd", f"linear_fwd[{sum(int(s[1]) for s in segs)}x{n_real}]"):
         _lib.check(_lib.lib().gn_linear_fwd(
             mode, n, ctypes.cast(ptrs, ctypes.c_void_p), a_lowp, ctypes.cast(lds, ctypes.c_void_p),
             ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(kpads, ctypes.c_void_p), M, _p(Wp), Kp, Npad, n_real,
@@ -401,7 +401,7 @@ def linear_wgrad(mode: int, dY: Tensor, n1: int, segs: Sequence[Seg], out: Optio
         db = torch.empty(n1, dtype=torch.float32, device=dev)
     if out is None:
         out = torch.empty((n1, ktot), dtype=torch.float32, device=dev)
-    with _timed("linear_wgrad"):
+    with _timed("linear_wgrad", f"linear_wgrad[{ktot}x{n1}]"):
         _lib.check(L.gn_linear_wgrad(mode, _p(dY), int(dY.dtype == torch.bfloat16), _rows(dY, "dY"), n1, n,
                                      ctypes.cast(ptrs, ctypes.c_void_p), x_lowp,
                                      ctypes.cast(lds, ctypes.c_void_p), ctypes.cast(widths, ctypes.c_void_p), M,

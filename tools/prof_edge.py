@@ -51,3 +51,4 @@ for _ in range(iters):
     if what in ("dq", "all"):
         ops.edgeconv_dq_gather(mode, g, dpre, H1p, dPQ[:, H1p:])
 print({k: (n, round(ms / n, 4)) for k, (n, ms) in ops.timer_summary().items()}, "N", N)
+
