@@ -229,6 +229,155 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_v2_kernel(
 #undef GN_G2_WRITE
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// C[M, N] (bf16) += A[M, K] . W[N, K]^T for 352 < K <= 704: the input gradient of a DynEdgeConv layer,
+// d_in += [dP | dQ] . [Wp | Wq]^T (models/components/layers.py:60 backward of the first Linear), in ONE pass over C
+// instead of two 352-wide accumulating launches (5 passes over C and 2 launches become 3 passes and 1).
+// Same streaming structure as gemm_nt_v2_kernel, re-blocked so that the stationary slice fits the registers at K = 704:
+// a wave owns 16 columns (v_mfma_f32_16x16x32_bf16: 22 k-steps x 4 registers = 88), a population is 8 waves x 16 = 128
+// columns, a tile is 32 rows (two 16-row MFMA blocks per wave; 45 KB of A per buffer).  HBM-bound:
+// M * (K * 2 + N * 4) bytes.
+constexpr int G3_ROWS = 32;
+template <int KS32, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_acc_wide_k_kernel(
+    const __bf16* __restrict__ A, long long lda, int M, int Kw,          // A rows: Kw real columns (% 8 == 0)
+    const __bf16* __restrict__ Wp, int Kp, int Npad, int N,               // Wp: [Npad][Kp] packed weights
+    __bf16* __restrict__ C, long long ldc, int ntiles, int nranges, int P)
+{
+    typedef float f32x4_v __attribute__((ext_vector_type(4)));
+    constexpr int NT = NW * 64;
+    constexpr int KB = KS32 * 64;                        // bytes of one A row in LDS
+    constexpr int AP = pitch4(KB);
+    constexpr int CW = NW * 16;                          // columns of one population
+    constexpr int SP = pitch4(CW * 4);                   // fp32 staging row
+    constexpr int ACH = KS32 * 4;                        // 16-byte chunks per A row
+    constexpr int ACPT = (G3_ROWS * ACH + NT - 1) / NT;
+    constexpr int OCH = CW / 8;                          // 16-byte chunks (8 bf16) per C row of the population
+    constexpr int OCPT = (G3_ROWS * OCH + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][G3_ROWS * AP];
+    __shared__ __attribute__((aligned(16))) unsigned char Stage[G3_ROWS * SP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int pop = slot % P, range = (slot / P) * 8 + xcd;
+    if (range >= nranges) return;
+    const int per = (ntiles + nranges - 1) / nranges;
+    int tile = range * per;
+    const int tile_end = min(ntiles, tile + per);
+    if (tile >= tile_end) return;
+    const int col0 = pop * CW;
+
+    // stationary W slice: row n = col0 + 16*wave + lr, k = 32*s + 8*lq .. +8
+    bf16x8 w2[KS32];
+    {
+        const int n = col0 + wave * 16 + lr;
+        const bool nok = n < Npad;
+        const __bf16* wrow = Wp + (long long)(nok ? n : 0) * Kp + lq * 8;
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(wrow + s * 32);
+            if (!nok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.0f;
+            }
+            w2[s] = v;
+        }
+    }
+
+    // A tiles are prefetched TWO tiles ahead through two register sets (a 32-row tile is short: one tile of MFMAs does
+    // not cover an HBM round trip)
+    u32x4 areg[2][ACPT];
+    bool a_ok[2][ACPT];
+#define GN_G3_LOAD(t_, set_)                                                                          \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < ACPT; ++i) {                                            \
+            const int id__ = tid + NT * i;                                                            \
+            const int row__ = id__ / ACH, c__ = id__ % ACH;                                           \
+            const long long m__ = (long long)(t_) * G3_ROWS + row__;                                  \
+            a_ok[set_][i] = (t_) < tile_end && id__ < G3_ROWS * ACH && m__ < M && c__ * 8 < Kw;       \
+            const long long off__ = a_ok[set_][i] ? m__ * lda + c__ * 8 : 0;                          \
+            areg[set_][i] = *reinterpret_cast<const u32x4*>(A + off__);                               \
+        }                                                                                             \
+    }
+#define GN_G3_WRITE(buf_, set_)                                                                       \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < ACPT; ++i) {                                            \
+            const int id__ = tid + NT * i;                                                            \
+            const int row__ = id__ / ACH, c__ = id__ % ACH;                                           \
+            if (id__ < G3_ROWS * ACH)                                                                 \
+                *reinterpret_cast<u32x4*>(&As[buf_][row__ * AP + c__ * 16]) =                         \
+                    a_ok[set_][i] ? areg[set_][i] : (u32x4){0u, 0u, 0u, 0u};                          \
+        }                                                                                             \
+    }
+// one tile: MFMAs on As[BUF_], old C rows, staging, next A tile (register set SET_) into As[BUF_ ^ 1], C update
+#define GN_G3_TILE(BUF_, SET_)                                                                        \
+    {                                                                                                 \
+        u32x4 creg[OCPT];                                                                             \
+        _Pragma("unroll") for (int i = 0; i < OCPT; ++i) {                                            \
+            const int id = tid + NT * i;                                                              \
+            const int row = id / OCH, c = id % OCH;                                                   \
+            const long long m = (long long)tile * G3_ROWS + row;                                      \
+            const int col = col0 + c * 8;                                                             \
+            const bool ok = id < G3_ROWS * OCH && m < M && col < N;                                   \
+            creg[i] = *reinterpret_cast<const u32x4*>(C + (ok ? m * ldc + col : 0));                  \
+        }                                                                                             \
+        f32x4_v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};                             \
+        {                                                                                             \
+            const unsigned char* p0 = &As[BUF_][lr * AP + lq * 16];                                   \
+            const unsigned char* p1 = p0 + 16 * AP;                                                   \
+            _Pragma("unroll") for (int s = 0; s < KS32; ++s) {                                        \
+                const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(p0 + s * 64);                      \
+                const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(p1 + s * 64);                      \
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[s], x0, acc0, 0, 0, 0);             \
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[s], x1, acc1, 0, 0, 0);             \
+            }                                                                                         \
+        }                                                                                             \
+        *reinterpret_cast<f32x4_v*>(&Stage[lr * SP + (wave * 16 + 4 * lq) * 4]) = acc0;               \
+        *reinterpret_cast<f32x4_v*>(&Stage[(16 + lr) * SP + (wave * 16 + 4 * lq) * 4]) = acc1;        \
+        GN_G3_WRITE((BUF_) ^ 1, SET_);                                                                \
+        __syncthreads();                                                                              \
+        _Pragma("unroll") for (int i = 0; i < OCPT; ++i) {                                            \
+            const int id = tid + NT * i;                                                              \
+            const int row = id / OCH, c = id % OCH;                                                   \
+            const long long m = (long long)tile * G3_ROWS + row;                                      \
+            const int col = col0 + c * 8;                                                             \
+            if (id < G3_ROWS * OCH && m < M && col < N) {                                             \
+                const f32x4_v lo4 = *reinterpret_cast<const f32x4_v*>(&Stage[row * SP + c * 32]);     \
+                const f32x4_v hi4 = *reinterpret_cast<const f32x4_v*>(&Stage[row * SP + c * 32 + 16]); \
+                const float nv[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]}; \
+                u32x4 v;                                                                              \
+                _Pragma("unroll") for (int w = 0; w < 4; ++w) {                                       \
+                    const unsigned int ow = creg[i][w];                                               \
+                    const float o0 = __builtin_bit_cast(float, ow << 16), o1 = __builtin_bit_cast(float, ow & 0xffff0000u); \
+                    v[w] = pk2(o0 + nv[2 * w], o1 + nv[2 * w + 1]);                                   \
+                }                                                                                     \
+                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(C + m * ldc + col)) = v;   \
+            }                                                                                         \
+        }                                                                                             \
+        __syncthreads();                                                                              \
+    }
+    GN_G3_LOAD(tile, 0);
+    GN_G3_WRITE(0, 0);
+    GN_G3_LOAD(tile + 1, 1);
+    __syncthreads();
+    // invariant at the top of an iteration: As[0] = tile, register set 1 = tile + 1 (in flight)
+    for (; tile < tile_end; tile += 2) {
+        GN_G3_LOAD(tile + 2, 0);
+        GN_G3_TILE(0, 1);                                // tile: As[0]; writes tile + 1 (set 1) into As[1]
+        ++tile;
+        if (tile < tile_end) {                           // workgroup-uniform
+            GN_G3_LOAD(tile + 2, 1);
+            GN_G3_TILE(1, 0);                            // tile + 1: As[1]; writes tile + 2 (set 0) into As[0]
+        }
+        --tile;
+    }
+#undef GN_G3_TILE
+#undef GN_G3_LOAD
+#undef GN_G3_WRITE
+}
+
 static bool g2_enabled() {
     const char* e = getenv("GN_DISABLE_V2");
     return !(e && e[0] == '1');
@@ -294,6 +443,24 @@ hipError_t launch_gemm_nt_v2(const Segs& a, int M, const void* Wp, int Kp, int N
                         return g2_launch<16, 8, __bf16, true>(A, lda, M, Kw, Wp, Kp, Npad, N, epi.bias, epi.gate, epi.ldgate, epi.relu, C, ldc, st); }
         if (ks <= 22) { if (22 * 16 > Kp) return hipErrorNotSupported;
                         return g2_launch<22, 8, __bf16, true>(A, lda, M, Kw, Wp, Kp, Npad, N, epi.bias, epi.gate, epi.ldgate, epi.relu, C, ldc, st); }
+        if (ks <= 44 && !epi.bias && !epi.relu && N % 128 == 0) {          // K up to 704: 16-column waves, 32-row tiles
+            const int ks32 = (Kw + 31) / 32;
+            const int P = N / 128;
+            const int ntiles = (M + G3_ROWS - 1) / G3_ROWS;
+            int slots = device_cus() / 8;
+            if (slots < P) slots = P;
+            const int rpx = slots / P, nranges = 8 * rpx;
+#define GN_G3_CASE(KS)                                                                                     \
+            {                                                                                              \
+                if ((KS) * 32 > Kp) return hipErrorNotSupported;                                           \
+                hipLaunchKernelGGL((gemm_nt_acc_wide_k_kernel<KS, 8>), dim3(8 * rpx * P), dim3(512), 0, st, (const __bf16*)A, lda, \
+                                   M, Kw, (const __bf16*)Wp, Kp, Npad, N, (__bf16*)C, ldc, ntiles, nranges, P); \
+                return hipGetLastError();                                                                  \
+            }
+            if (ks32 <= 16) GN_G3_CASE(16);
+            if (ks32 <= 22) GN_G3_CASE(22);
+#undef GN_G3_CASE
+        }
         return hipErrorNotSupported;
     }
     if (out_lowp) {

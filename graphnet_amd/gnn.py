@@ -355,15 +355,13 @@ class _DynEdgeFunction(torch.autograd.Function):
             grads[4 * l + 3] = db2
             if l > 0:
                 Wa, Wb = W1[:, :Fin], W1[:, Fin:]
-                # d_in += dP . (Wa - Wb) + dQ . Wb as two K = H1p contractions (each weights-stationary) that
-                # accumulate into the skip-cat gradient of the producing layer
-                WpT = wb.get(("WpT", l), (ops.round_up(Fin, 128), ops.round_up(H1p, ku)), dt, dev)
-                WqT = wb.get(("WqT", l), (ops.round_up(Fin, 128), ops.round_up(H1p, ku)), dt, dev)
-                wb.copy(WpT[:Fin, :H1], Wa.t(), Wb.t())
-                wb.copy(WqT[:Fin, :H1], Wb.t())
+                # d_in += [dP | dQ] . [(Wa - Wb) | Wb]: one K = 2 H1p contraction (weights-stationary, csrc/gemm_v2.hip)
+                # that accumulates into the skip-cat gradient of the producing layer - one pass over d_in, not two
+                WpqT = wb.get(("WpqT", l), (ops.round_up(Fin, 128), ops.round_up(2 * H1p, ku)), dt, dev)
+                wb.copy(WpqT[:Fin, :H1], Wa.t(), Wb.t())
+                wb.copy(WpqT[:Fin, H1p:H1p + H1], Wb.t())
                 d_in = dXcat[:, seg_off[l]: seg_off[l] + Fin]
-                ops.linear_fwd(mode, [(dPQ[:, :H1p], H1p)], WpT, Fin, out=d_in, accum=True)
-                ops.linear_fwd(mode, [(dPQ[:, H1p:], H1p)], WqT, Fin, out=d_in, accum=True)
+                ops.linear_fwd(mode, [(dPQ, 2 * H1p)], WpqT, Fin, out=d_in, accum=True)
         wb.end("bwd", dev)
         return (None, None) + tuple(grads)
 
