@@ -652,6 +652,10 @@ def main():
                               "executed_frac": flops_exec * args.steps / dt / 1e12 / peak,
                               "note": "per GPU; executed_frac is the MFMA utilisation of the step"},
             "phase_ms_per_step": {k: v[1] / prof_steps for k, v in sorted(timers.items(), key=lambda kv: -kv[1][1])},
+            # the same HIP-event pairs keyed by kernel shape ([H1p x H2] of an edge kernel, [K x N] of a GEMM): (launches per
+            # step, ms per launch)
+            "kernel_shape_ms": {k: [v[0] / prof_steps, v[1] / max(v[0], 1)]
+                                for k, v in sorted(detail.items(), key=lambda kv: -kv[1][1])},
             "launch": launch, "host_issue_ms": host_issue_ms,
             "final_loss": float(loss.detach()),
             "measured_peaks": (_log("yardsticks: library GEMM, device copy"), measured_peaks(dev))[1],
