@@ -660,6 +660,51 @@ def test_persistent_kernels_match_generic_kernels(oracle):
         close(res["v2"]["dpre"][:nrows], res["v1"]["dpre"][:nrows], "dpre")
 
 
+@pytest.mark.parametrize("sizes", [[1], [3], [2, 9], [65], [7, 1, 130]])
+@pytest.mark.parametrize("kk,H1", [(8, 336), (8, 128), (12, 352)])
+def test_persistent_kernels_on_tiny_batches(sizes, kk, H1):
+    """The persistent bf16 edge kernels on batches smaller than one tile range: single pulses, events with fewer pulses
+    than k (empty slots), a pulse count that is not a multiple of the 8 (4) centres of a tile.  Their loops look two
+    or three tiles ahead without branches (clamped loads, slack rows in the saved buffer): every result must still
+    equal the generic kernels' on the same inputs, and nothing may be read or written out of bounds."""
+    import os
+    from graphnet_amd import ops
+    mode, dt, F, H2 = 1, torch.bfloat16, 32, 256
+    gen = torch.Generator().manual_seed(100 + sum(sizes) + kk)
+    N = sum(sizes)
+    x3 = torch.randn(N, 3, generator=gen)
+    ptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32)
+    batch = torch.repeat_interleave(torch.arange(len(sizes), dtype=torch.int32), torch.tensor(sizes))
+    g = ops.knn_graph(x3.to(DEV), [0, 1, 2], batch.to(DEV), ptr.to(DEV), kk)
+    H1p = ops.round_up(H1, 32)
+    PQ = (torch.randn(N, 2 * H1p, generator=gen) * 0.5).to(DEV).to(dt)
+    PQ[:, H1:H1p] = 0
+    PQ[:, H1p + H1:] = 0
+    W2 = (torch.randn(H2, H1, generator=gen) * 0.1).to(DEV)
+    b2 = (torch.randn(H2, generator=gen) * 0.1).to(DEV)
+    W2p, W2Tp = ops.pack_weight(W2, [H1], dt), ops.pack_weight(W2.t().contiguous(), [H2], dt)
+    gout = torch.randn(N, H2, generator=gen).to(DEV).to(dt)
+    res = {}
+    for tag, flag in (("v2", "0"), ("v1", "1")):
+        os.environ["GN_DISABLE_V2"] = flag
+        try:
+            out, saved = ops.edgeconv_fwd(mode, g, PQ, H1p, W2p, b2, H2, H1=H1)
+            dW2, db2 = ops.edgeconv_dw2(mode, g, PQ, H1p, H1, H2, gout, saved)
+            dPQ = torch.zeros(N, 2 * H1p, dtype=dt, device=DEV)
+            dpre = torch.zeros(max(g.rows, 1), H1p, dtype=dt, device=DEV)
+            ops.edgeconv_bwd(mode, g, PQ, H1p, H2, gout, saved, W2Tp, dpre, dPQ[:, :H1p])
+            ops.edgeconv_dq_gather(mode, g, dpre, H1p, dPQ[:, H1p:])
+            torch.cuda.synchronize()
+        finally:
+            os.environ["GN_DISABLE_V2"] = "0"
+        res[tag] = dict(out=out.float(), dW2=dW2, db2=db2, dPQ=dPQ.float())
+    for k in ("out", "dW2", "db2", "dPQ"):
+        a, c = res["v2"][k], res["v1"][k]
+        assert torch.isfinite(a).all()
+        scale = float(c.abs().max()) + 1e-6
+        assert float((a - c).abs().max()) <= 2e-2 * scale, (sizes, kk, H1, k, float((a - c).abs().max()), scale)
+
+
 @pytest.mark.parametrize("name,mode,tol", MODES)
 def test_dynedge_as_embedded_in_deepice(oracle, name, mode, tol):
     """The DynEdge that ``DeepIce(include_dynedge=True)`` embeds (``models/gnn/icemix.py:100-118``): 9 neighbours in
