@@ -7,7 +7,7 @@ import json, sqlite3, sys
 EVENTS = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 GROUPS = {  # op group of bench.py -> substring of its dominant kernel
     "edgeconv_fwd": "edge_fwd_ws_kernelILi22", "edgeconv_bwd": "edge_bwd_v2_kernelILi11",
-    "edgeconv_dw2": "edge_dw2_v2_kernelILi11", "edgeconv_dq_gather": "dq_gather_kernel",
+    "edgeconv_dw2": "edge_dw2_v3_kernelILi11", "edgeconv_dq_gather": "dq_gather_kernel",
     "linear_fwd": "gemm_nt_v2_kernelILi16ELi11", "linear_wgrad": "gemm_tn_v2_kernel", "knn_graph": "knn_kernel",
 }
 def per_kernel(db, counter):
@@ -33,7 +33,7 @@ for grp, sub in GROUPS.items():
                         f"separate --pmc passes over bench.py, B={EVENTS}"}
 import subprocess
 try:
-    out["_commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True,
+    out["_commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
                                     cwd=__import__("os").path.dirname(__import__("os").path.abspath(__file__))).stdout.strip() or \
         __import__("os").environ.get("GN_COMMIT", "unknown")
 except Exception:
