@@ -1425,39 +1425,40 @@ __global__ __launch_bounds__((NB1 > 8 ? NB1 : 8) * 64) void edge_bwd_v2_kernel(
             zero_acc(a0); zero_acc(a1);
             const unsigned char* p0 = &Ds[buf][r * DP + h * 16];
             const unsigned char* p1 = p0 + 32 * DP;
+            const int nb = wave;
+            // ---- epilogue pieces: (.) [h > 0] -> dpre tile in LDS; lane = edge row r of the row block,
+            //      registers 4g..4g+3 = columns 8g + 4h + (0..3) of this wave's 32-column block
+            auto epi_group = [&](const f32x16& acc, int rb, int gq, unsigned int wsh) {
+                unsigned char* srow = &Stage[(rb * 32 + r) * SP + (nb * 32 + 4 * h) * 2];
+                float d[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float av = acc[4 * gq + j];          // copy the element before any bit_cast
+                    const int m = __builtin_amdgcn_sbfe((int)wsh, 8 * gq + j, 1);   // 0 / -1 from bit 8gq+j (v_bfe_i32: one op)
+                    if constexpr (V == 0) d[j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, av) & (unsigned int)m);
+                    else d[j] = m ? av : 0.01f * av;           // leaky relu: slope 1 where h > 0, 0.01 elsewhere
+                }
+                typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                const u32x2_t pk = {pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
+                *reinterpret_cast<u32x2_t*>(srow + 16 * gq) = pk;
+            };
+            // the chain of row block 0 first; the chain of row block 1 carries the epilogue of block 0 between its
+            // MFMAs (one 4-column group every KS2 / 4 steps), so that only block 1's epilogue runs with the matrix pipe idle
 #pragma unroll
             for (int s = 0; s < KS2; ++s) {
                 const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(p0 + s * 32);
-                const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(p1 + s * 32);
                 a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s], f0, a0, 0, 0, 0);    // a[n][row]
+            }
+            const unsigned int wsh0 = Hb[buf][r * NB1 + nb] >> (4 * h);
+            const unsigned int wsh1 = Hb[buf][(32 + r) * NB1 + nb] >> (4 * h);
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(p1 + s * 32);
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s], f1, a1, 0, 0, 0);
+                if (s % (KS2 / 4) == 1) epi_group(a0, 0, s / (KS2 / 4), wsh0);
             }
-
-            // ---- epilogue: (.) [h > 0] -> dpre tile in LDS; lane = edge row r of the row block,
-            //      registers 4g..4g+3 = columns 8g + 4h + (0..3) of this wave's 32-column block
-            const int nb = wave;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                const f32x16& acc = rb ? a1 : a0;
-                const int rl = rb * 32 + r;
-                const unsigned int wsh = Hb[buf][rl * NB1 + nb] >> (4 * h);
-                unsigned char* srow = &Stage[rl * SP + (nb * 32 + 4 * h) * 2];
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    float d[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float av = acc[4 * gq + j];          // copy the element before any bit_cast
-                        int m;                                     // 0 / -1 from bit 8gq+j (v_bfe_i32: one op)
-                        m = __builtin_amdgcn_sbfe((int)wsh, 8 * gq + j, 1);
-                        if constexpr (V == 0) d[j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, av) & (unsigned int)m);
-                        else d[j] = m ? av : 0.01f * av;           // leaky relu: slope 1 where h > 0, 0.01 elsewhere
-                    }
-                    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-                    const u32x2_t pk = {pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
-                    *reinterpret_cast<u32x2_t*>(srow + 16 * gq) = pk;
-                }
-            }
+            for (int gq = 0; gq < 4; ++gq) epi_group(a1, 1, gq, wsh1);
             // ---- slot sums on the matrix core: dP^T[n][c] = sum_rows dpre[row][n] * [row / 8 == c]
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // own LDS writes before own reads
             f32x16 a2;
