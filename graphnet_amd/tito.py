@@ -134,10 +134,16 @@ class _DynTransFunction(torch.autograd.Function):
         df = ops.dropout(dz3, drop[1][3], th, out=torch.empty_like(dz3, dtype=ops.mode_dtype(mode))) if drop else dz3g
         grads[12], grads[13] = ops.linear_wgrad(mode, df, d, _ksegs([(h, F)]), with_bias=True)
         dh = ops.linear_fwd(mode, _ksegs([(df, d)]), _wt(mode, Wl2.t(), [d]), F, gate=h, out_lowp=h.dtype == torch.bfloat16)
-        if drop:                # dropped hidden units are 0 in h (gate closed); the kept ones carry the 1/(1-p)
-            ops.dropout(dh, drop[1][2], th, out=dh)
+        # dropout on the hidden layer, backward: h is the POST-dropout activation, so the gate (h > 0) above is already
+        # closed on every dropped unit; what is left of dropout's backward is the factor 1 / (1 - p) on the kept ones.
+        # Both consumers of dh are linear in it: the factor goes into the weight gradient and into the packed Wl1^T
+        # (two tiny tensors) instead of a pass over the [N, 2048] tensor with a hash per element.
+        inv = 1.0 / (1.0 - th / 4294967296.0) if drop else 1.0
         grads[10], grads[11] = ops.linear_wgrad(mode, dh, F, _ksegs([(y1, d)]), with_bias=True)
-        ops.linear_fwd(mode, _ksegs([(dh, F)]), _wt(mode, Wl1.t(), [F]), d, out=dz3, accum=True)      # dy1
+        if drop:
+            grads[10] = grads[10] * inv
+            grads[11] = grads[11] * inv
+        ops.linear_fwd(mode, _ksegs([(dh, F)]), _wt(mode, Wl1.t() * inv if drop else Wl1.t(), [F]), d, out=dz3, accum=True)      # dy1
         # norm1, attention
         dz1, grads[14], grads[15] = ops.rownorm_act_bwd(dz3, z1, d, "identity", g1, be1, st1,
                                                         lowp="both" if lp and not drop else "no")

@@ -42,6 +42,8 @@ print(f"config4 dropout={p_drop} B={B} N={b.x.shape[0]} (pulses/event {int(n.min
       f"{1e3*dt:.1f} ms/step  {B/dt:.1f} events/s  {b.x.shape[0]/dt/1e6:.2f} Mpulses/s  loss {float(l):.4f}")
 summary = ops.timer_summary()
 print({k: round(ms / steps, 3) for k, (n_, ms) in summary.items()})
+print("per kernel shape (launches per step, ms per launch):",
+      {k: (n_ / steps, round(ms / max(n_, 1), 4)) for k, (n_, ms) in sorted(ops.timer_summary(detail=True).items(), key=lambda kv: -kv[1][1])})
 # one JSON line in the shape of bench.py's (BASELINE configs[3] has no bench.py leg): throughput + the roofline of the
 # dominant kernel family, the ragged self attention, priced at 4 * sum(n_i^2) * d_model FLOP per layer forward
 # (Q K^T and P V, 2 FLOP per MAC) and 2.5x that backward (dQ, dK, dV, dP recomputation), against the dense bf16 peak
