@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphnet_amd.so")
 _lib = None
-ABI_VERSION = 3          # GN_ABI_VERSION of include/graphnet_amd.h these signatures mirror
+ABI_VERSION = 4          # GN_ABI_VERSION of include/graphnet_amd.h these signatures mirror
 
 P = c_void_p
 I32 = c_int32
@@ -70,6 +70,8 @@ SIGNATURES = {
     "gn_attention_plan": (I32, [P, I32, P, I32, P]),
     "gn_attention_fwd": (I32, [I32, P, I64, I32, I32, P, P, I32, I32, P, I64, P, U32, U32, P]),
     "gn_attention_bwd": (I32, [I32, P, I64, I32, I32, P, P, I32, I32, P, I64, P, I64, P, P, P, I64, U32, U32, P]),
+    "gn_attention_fwd_bits": (I32, [P, I64, I32, I32, P, P, I32, I32, P, I64, P, U32, U32, P, P, P, I64, P]),
+    "gn_attention_bwd_bits": (I32, [P, I64, I32, I32, P, P, I32, I32, P, I64, P, I64, P, P, P, I64, U32, P, P, P, I64, P]),
     "gn_bn_blocks": (I64, [I64]),
     "gn_bn_sums": (I32, [I32, I32, P, I64, I64, I32, P, P, I64, P, P, P, P, P, P, P]),
     "gn_bn_finalize": (I32, [P, P, I32, c_float, P, P, P, P]),

@@ -349,10 +349,25 @@ __device__ __forceinline__ bf16x8 attn_tr_frag(const unsigned char* tile, int pi
     return __builtin_bit_cast(bf16x8, av);
 }
 
-template <int NB, bool DROP>
+// Saved dropout decisions of the matrix-core kernels.  The keep rule is a hash of (stream, query, key, head): ~13 vector
+// instructions per probability, and the backward needs every decision twice more (dQ pass, dK/dV pass) - with dropout
+// 0.1 the hash was 40 % of the attention time.  The forward now stores its decisions as bits, once per orientation:
+//   r: tile (query block qb, key block kb) of an event = 32 words, word c = the 32 key bits of query 32 qb + c
+//   c: tile (key block kb, query block qb)            = 32 words, word c = the 32 query bits of key 32 kb + c
+// (tile index = evoff[event] + first * W + second, W = ceil(n / 32); one plane of `plane` words per head), so that the
+// dQ pass (a lane owns a query) and the dK/dV pass (a lane owns a key) each read ONE coalesced word per lane and
+// 32 x 32 block, a block ahead, and spend 3 instructions per probability.  The forward kernel writes the row words (its
+// lanes own queries); attn_bits_transpose_kernel turns every 32 x 32 bit tile into the column words (HBM-bound, ~0.1 ms).
+struct DropBits { unsigned int* r; unsigned int* c; const long long* evoff; long long plane; };
+// keep mask (0 / ~0) of accumulator register q from the word of this lane, pre-shifted by 4 * h
+__device__ __forceinline__ unsigned int attn_keep_mask(unsigned int wsh, int q) {
+    return (unsigned int)__builtin_amdgcn_sbfe((int)wsh, acc_row(q, 0), 1);
+}
+
+template <int NB, bool DROP, bool BITS = false>
 __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(
     const __bf16* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
-    int B, float scale2, __bf16* __restrict__ out, long long ldo, float* __restrict__ lse2, Drop dr) {
+    int B, float scale2, __bf16* __restrict__ out, long long ldo, float* __restrict__ lse2, Drop dr, DropBits db) {
     constexpr int DH = 32 * NB, KS = DH / 16, VP = attn_tr_pitch(DH * 2);
     __shared__ __attribute__((aligned(16))) unsigned char Vs[32 * VP];
     const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
@@ -414,12 +429,24 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(
             const float mn = fmaxf(m[g], mx * scale2);
             const float corr = exp2f(m[g] - mn);
             float ps = 0.0f;
+            unsigned int roww = 0u;                     // BITS: this lane's 16 keep decisions, bit = key - kt - 4h
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 s[r] = exp2f(fmaf(s[r], scale2, -mn));
                 ps += s[r];
-                if constexpr (DROP)
-                    s[r] = gn_keep(dr.seed, (unsigned)(q0 + 32 * g + c), (unsigned)((kt + acc_row(r, h)) * H + head), dr.thresh) ? s[r] * dr.inv : 0.0f;
+                if constexpr (DROP) {
+                    const bool keep = gn_keep(dr.seed, (unsigned)(q0 + 32 * g + c), (unsigned)((kt + acc_row(r, h)) * H + head), dr.thresh);
+                    s[r] = keep ? s[r] * dr.inv : 0.0f;
+                    if constexpr (BITS) roww |= keep ? (1u << acc_row(r, 0)) : 0u;
+                }
+            }
+            if constexpr (BITS) {
+                if (q0 + 32 * g < kend) {                // uniform; (a tile's second query block may lie past the event)
+                    const int W = (kend - kbeg + 31) >> 5, qb = ((q0 - kbeg) >> 5) + g, kb = (kt - kbeg) >> 5;
+                    roww <<= 4 * h;
+                    roww |= (unsigned int)__shfl_xor((int)roww, 32);
+                    if (h == 0) db.r[db.plane * head + (db.evoff[e] + (long long)qb * W + kb) * 32 + c] = roww;
+                }
             }
             l[g] = l[g] * corr + ps;
             m[g] = mn;
@@ -456,11 +483,11 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(
     }
 }
 
-template <int NB, bool DROP>
+template <int NB, bool DROP, bool BITS = false>
 __global__ __launch_bounds__(64) void attn_bwd_dq_mfma_kernel(
     const __bf16* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
     int B, float scale, const __bf16* __restrict__ out, long long ldo, const __bf16* __restrict__ dout, long long lddo,
-    const float* __restrict__ lse2, float* __restrict__ delta, __bf16* __restrict__ dqkv, long long lddq, Drop dr) {
+    const float* __restrict__ lse2, float* __restrict__ delta, __bf16* __restrict__ dqkv, long long lddq, Drop dr, DropBits db) {
     constexpr int DH = 32 * NB, KS = DH / 16, VP = attn_tr_pitch(DH * 2);
     __shared__ __attribute__((aligned(16))) unsigned char Ks[32 * VP];
     const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
@@ -499,6 +526,17 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_mfma_kernel(
 #pragma unroll
         for (int s = 0; s < KS; ++s) { kn[s] = attn_ld8(kp + 16 * s + 8 * h); vn[s] = attn_ld8(kp + E + 16 * s + 8 * h); }
     }
+    const unsigned int* wrow[2] = {nullptr, nullptr};   // BITS: word c of tile (query block, key block 0) of this lane
+    unsigned int wnext[2] = {0u, 0u};
+    if constexpr (BITS) {
+        const int W = (kend - kbeg + 31) >> 5;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int qb = min(((q0 - kbeg) >> 5) + g, W - 1);                  // (past the event: any valid word)
+            wrow[g] = db.r + db.plane * head + (db.evoff[e] + (long long)qb * W) * 32 + c;
+            wnext[g] = wrow[g][0];
+        }
+    }
     for (int kt = kbeg; kt < kend; kt += 32) {
         bf16x8 kf[KS], vf[KS];
 #pragma unroll
@@ -514,6 +552,15 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_mfma_kernel(
         __syncthreads();
         const bool tail = kt + 32 > kend;
         bf16x8 df[2][2];
+        unsigned int wsh[2] = {0u, 0u};                 // saved decisions: this lane's row word of the block, >> 4h
+        if constexpr (BITS) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) wsh[g] = wnext[g] >> (4 * h);
+            if (kt + 32 < kend) {                        // next block's words (in flight during this block's work)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) wnext[g] = wrow[g][((kt + 32 - kbeg) >> 5) * 32];
+            }
+        }
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             f32x16 s, dp;
@@ -528,8 +575,14 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_mfma_kernel(
                 float p = exp2f(fmaf(s[r], scale2, -ls[g]));
                 if (tail && kt + acc_row(r, h) >= kend) p = 0.0f;
                 float dpr = dp[r];
-                if constexpr (DROP)
-                    dpr = gn_keep(dr.seed, (unsigned)(q0 + 32 * g + c), (unsigned)((kt + acc_row(r, h)) * H + head), dr.thresh) ? dpr * dr.inv : 0.0f;
+                if constexpr (DROP) {
+                    if constexpr (BITS) {
+                        const float sc = dpr * dr.inv;
+                        dpr = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, sc) & attn_keep_mask(wsh[g], r));
+                    } else {
+                        dpr = gn_keep(dr.seed, (unsigned)(q0 + 32 * g + c), (unsigned)((kt + acc_row(r, h)) * H + head), dr.thresh) ? dpr * dr.inv : 0.0f;
+                    }
+                }
                 s[r] = p * (dpr - dl[g]);
             }
             df[g][0] = attn_pack8(s, 0);
@@ -559,11 +612,11 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_mfma_kernel(
     }
 }
 
-template <int NB, bool DROP>
+template <int NB, bool DROP, bool BITS = false>
 __global__ __launch_bounds__(64) void attn_bwd_dkv_mfma_kernel(
     const __bf16* __restrict__ qkv, long long ld, int H, const int* __restrict__ ptr, const int* __restrict__ tile_ptr,
     int B, float scale, const __bf16* __restrict__ dout, long long lddo, const float* __restrict__ lse2,
-    const float* __restrict__ delta, __bf16* __restrict__ dqkv, long long lddq, Drop dr) {
+    const float* __restrict__ delta, __bf16* __restrict__ dqkv, long long lddq, Drop dr, DropBits db) {
     constexpr int DH = 32 * NB, KS = DH / 16, VP = attn_tr_pitch(DH * 2);
     __shared__ __attribute__((aligned(16))) unsigned char Qs[32 * VP];
     __shared__ __attribute__((aligned(16))) unsigned char Gs[32 * VP];
@@ -603,6 +656,17 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_mfma_kernel(
         }
         ln = lse2[(long long)qrow * H + head]; dn = delta[(long long)qrow * H + head];
     }
+    const unsigned int* wcol[2] = {nullptr, nullptr};   // BITS: word c of tile (key block, query block 0) of this lane
+    unsigned int wnext[2] = {0u, 0u};
+    if constexpr (BITS) {
+        const int W = (kend - kbeg + 31) >> 5;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int kb = min(((k0 - kbeg) >> 5) + g, W - 1);
+            wcol[g] = db.c + db.plane * head + (db.evoff[e] + (long long)kb * W) * 32 + c;
+            wnext[g] = wcol[g][0];
+        }
+    }
     for (int qt = kbeg; qt < kend; qt += 32) {
         bf16x8 qa[KS], ga[KS];
 #pragma unroll
@@ -635,6 +699,15 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_mfma_kernel(
             Dr[4 * j] = D4.x; Dr[4 * j + 1] = D4.y; Dr[4 * j + 2] = D4.z; Dr[4 * j + 3] = D4.w;
         }
         bf16x8 pf[2][2], df[2][2];
+        unsigned int wsh[2] = {0u, 0u};                 // saved decisions: this lane's column word of the block, >> 4h
+        if constexpr (BITS) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) wsh[g] = wnext[g] >> (4 * h);
+            if (qt + 32 < kend) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) wnext[g] = wcol[g][((qt + 32 - kbeg) >> 5) * 32];
+            }
+        }
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             f32x16 s, dp;
@@ -650,9 +723,15 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_mfma_kernel(
                 if (tail && qt + acc_row(r, h) >= kend) p = 0.0f;
                 float pd = p, dpr = dp[r];
                 if constexpr (DROP) {
-                    const bool keep = gn_keep(dr.seed, (unsigned)(qt + acc_row(r, h)), (unsigned)((k0 + 32 * g + c) * H + head), dr.thresh);
-                    pd = keep ? p * dr.inv : 0.0f;
-                    dpr = keep ? dpr * dr.inv : 0.0f;
+                    if constexpr (BITS) {
+                        const unsigned int km = attn_keep_mask(wsh[g], r);
+                        pd = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, p * dr.inv) & km);
+                        dpr = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, dpr * dr.inv) & km);
+                    } else {
+                        const bool keep = gn_keep(dr.seed, (unsigned)(qt + acc_row(r, h)), (unsigned)((k0 + 32 * g + c) * H + head), dr.thresh);
+                        pd = keep ? p * dr.inv : 0.0f;
+                        dpr = keep ? dpr * dr.inv : 0.0f;
+                    }
                 }
                 s[r] = pd;
                 dp[r] = p * (dpr - Dr[r]);
@@ -689,6 +768,52 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_mfma_kernel(
     }
 }
 
+// bits_c from bits_r: every 32 x 32 bit tile (query block, key block) of an event, transposed into the tile
+// (key block, query block).  Launched on the attention grid (one wave per 64-query tile and head, the plan's event
+// lookup once per wave): half-wave g owns query block 2 * tile + g and walks its key blocks; lane j holds row j of a
+// tile, five exchange steps (rows j and j ^ s swap the off-diagonal s x s bit blocks) leave column j in lane j.
+// HBM-bound: every word is read once and written once in 128-byte pieces.
+__global__ __launch_bounds__(64) void attn_bits_transpose_kernel(const unsigned int* __restrict__ bits_r,
+                                                                unsigned int* __restrict__ bits_c,
+                                                                const long long* __restrict__ evoff, const int* __restrict__ ptr,
+                                                                const int* __restrict__ tile_ptr, int B, long long plane) {
+    const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
+    if (tile >= tile_ptr[B]) return;
+    const int es = attn_event_of_tile(tile_ptr, B, tile);
+    const int e = tile_ptr[B + 1 + es];
+    const int n = ptr[e + 1] - ptr[e];
+    const int W = (n + 31) >> 5;
+    const int qb = (tile - tile_ptr[es]) * 2 + (lane >> 5), j = lane & 31;
+    if (qb >= W) return;                                 // (half-wave uniform; __shfl_xor below stays inside a half)
+    const unsigned int* src = bits_r + plane * head + (evoff[e] + (long long)qb * W) * 32 + j;
+    unsigned int* dst = bits_c + plane * head + (evoff[e] + qb) * 32 + j;
+    // rows with (j & s) == 0 keep the columns with (k & s) == 0 and take the others from the partner row, and vice versa
+#define GN_BT_STEP(x_, s_, m_)                                                                        \
+    {                                                                                                 \
+        const unsigned int p = (unsigned int)__shfl_xor((int)(x_), s_, 32);                           \
+        (x_) = (j & (s_)) ? (((x_) & ~(m_)) | ((p >> (s_)) & (m_))) : (((x_) & (m_)) | ((p << (s_)) & ~(m_))); \
+    }
+    int kb = 0;
+    for (; kb + 4 <= W; kb += 4) {                       // four tiles in flight
+        unsigned int x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = src[(long long)(kb + u) * 32];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            GN_BT_STEP(x[u], 16, 0x0000ffffu) GN_BT_STEP(x[u], 8, 0x00ff00ffu) GN_BT_STEP(x[u], 4, 0x0f0f0f0fu)
+            GN_BT_STEP(x[u], 2, 0x33333333u) GN_BT_STEP(x[u], 1, 0x55555555u)
+            dst[(long long)(kb + u) * W * 32] = x[u];
+        }
+    }
+    for (; kb < W; ++kb) {
+        unsigned int x = src[(long long)kb * 32];
+        GN_BT_STEP(x, 16, 0x0000ffffu) GN_BT_STEP(x, 8, 0x00ff00ffu) GN_BT_STEP(x, 4, 0x0f0f0f0fu)
+        GN_BT_STEP(x, 2, 0x33333333u) GN_BT_STEP(x, 1, 0x55555555u)
+        dst[(long long)kb * W * 32] = x;
+    }
+#undef GN_BT_STEP
+}
+
 static bool attn_shape_ok(int DH, long long ld, long long ldo) {
     return (DH == 8 || DH == 16 || DH == 32 || DH == 64) && ld % 4 == 0 && ldo % 4 == 0;
 }
@@ -707,6 +832,7 @@ static Drop make_drop(unsigned seed, unsigned thresh) {
 
 hipError_t launch_attn_fwd(int lowp, const void* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
                            int B, int N, void* out, long long ldo, float* lse2, unsigned seed, unsigned thresh,
+                           unsigned int* bits_r, unsigned int* bits_c, const long long* evoff, long long plane,
                            hipStream_t st) {
     if (N == 0 || B == 0) return hipSuccess;
     const dim3 grid((unsigned)(N / ATT_TILE + B), (unsigned)H), block(ATT_TILE);
@@ -716,10 +842,14 @@ hipError_t launch_attn_fwd(int lowp, const void* qkv, long long ld, int H, int D
     if ((long long)N * H >= (1ll << 32)) return hipErrorInvalidValue;      // dropout counters are 32-bit
     if (lowp) {                                           // bf16 tensors, matrix core
         if ((DH != 32 && DH != 64) || ld % 8 || ldo % 8) return hipErrorInvalidValue;
-#define GN_ATTM(NB_, DR_) hipLaunchKernelGGL((attn_fwd_mfma_kernel<NB_, DR_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, B, scale2, (__bf16*)out, ldo, lse2, dr)
-        if (DH == 32) { if (drop) GN_ATTM(1, true); else GN_ATTM(1, false); }
-        else { if (drop) GN_ATTM(2, true); else GN_ATTM(2, false); }
+        const DropBits db = {drop ? bits_r : nullptr, drop ? bits_c : nullptr, evoff, plane};
+        if (db.r && (!db.c || !evoff)) return hipErrorInvalidValue;
+#define GN_ATTM(NB_, DR_, BI_) hipLaunchKernelGGL((attn_fwd_mfma_kernel<NB_, DR_, BI_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, B, scale2, (__bf16*)out, ldo, lse2, dr, db)
+        if (DH == 32) { if (db.r) GN_ATTM(1, true, true); else if (drop) GN_ATTM(1, true, false); else GN_ATTM(1, false, false); }
+        else { if (db.r) GN_ATTM(2, true, true); else if (drop) GN_ATTM(2, true, false); else GN_ATTM(2, false, false); }
 #undef GN_ATTM
+        if (db.r && plane > 0)                           // the column-oriented copy for the dK / dV pass
+            hipLaunchKernelGGL(attn_bits_transpose_kernel, grid, block, 0, st, bits_r, bits_c, evoff, ptr, tile_ptr, B, plane);
         return hipGetLastError();
     }
     if (!attn_shape_ok(DH, ld, ldo)) return hipErrorInvalidValue;
@@ -734,6 +864,7 @@ hipError_t launch_attn_fwd(int lowp, const void* qkv, long long ld, int H, int D
 hipError_t launch_attn_bwd(int lowp, const void* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
                            int B, int N, const void* out, long long ldo, const void* dout, long long lddo,
                            const float* lse2, float* delta, void* dqkv, long long lddq, unsigned seed, unsigned thresh,
+                           const unsigned int* bits_r, const unsigned int* bits_c, const long long* evoff, long long plane,
                            hipStream_t st) {
     if (N == 0 || B == 0) return hipSuccess;
     const dim3 grid((unsigned)(N / ATT_TILE + B), (unsigned)H), block(ATT_TILE);
@@ -743,15 +874,18 @@ hipError_t launch_attn_bwd(int lowp, const void* qkv, long long ld, int H, int D
     if ((long long)N * H >= (1ll << 32)) return hipErrorInvalidValue;
     if (lowp) {
         if ((DH != 32 && DH != 64) || ld % 8 || ldo % 8 || lddo % 8 || lddq % 8) return hipErrorInvalidValue;
-#define GN_ATTM(NB_, DR_)                                                                                           \
+        const DropBits db = {drop ? const_cast<unsigned int*>(bits_r) : nullptr, drop ? const_cast<unsigned int*>(bits_c) : nullptr,
+                             evoff, plane};
+        if ((db.r != nullptr) != (db.c != nullptr) || (db.r && !evoff)) return hipErrorInvalidValue;
+#define GN_ATTM(NB_, DR_, BI_)                                                                                      \
     {                                                                                                               \
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NB_, DR_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, \
-                           B, scale, (const __bf16*)out, ldo, (const __bf16*)dout, lddo, lse2, delta, (__bf16*)dqkv, lddq, dr); \
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<NB_, DR_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, \
-                           B, scale, (const __bf16*)dout, lddo, lse2, delta, (__bf16*)dqkv, lddq, dr);              \
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NB_, DR_, BI_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, \
+                           B, scale, (const __bf16*)out, ldo, (const __bf16*)dout, lddo, lse2, delta, (__bf16*)dqkv, lddq, dr, db); \
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<NB_, DR_, BI_>), grid, block, 0, st, (const __bf16*)qkv, ld, H, ptr, tile_ptr, \
+                           B, scale, (const __bf16*)dout, lddo, lse2, delta, (__bf16*)dqkv, lddq, dr, db);          \
     }
-        if (DH == 32) { if (drop) GN_ATTM(1, true) else GN_ATTM(1, false) }
-        else { if (drop) GN_ATTM(2, true) else GN_ATTM(2, false) }
+        if (DH == 32) { if (db.r) GN_ATTM(1, true, true) else if (drop) GN_ATTM(1, true, false) else GN_ATTM(1, false, false) }
+        else { if (db.r) GN_ATTM(2, true, true) else if (drop) GN_ATTM(2, true, false) else GN_ATTM(2, false, false) }
 #undef GN_ATTM
         return hipGetLastError();
     }

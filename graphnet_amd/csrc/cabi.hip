@@ -321,10 +321,20 @@ int gn_attention_fwd(int32_t lowp, const void* qkv, int64_t ld, int32_t H, int32
                      uint32_t drop_thresh, void* stream) {
     if (H <= 0 || B < 0 || N < 0) return bad("gn_attention_fwd", "H > 0, B >= 0, N >= 0");
     hipError_t r = gn::launch_attn_fwd(lowp, qkv, ld, H, DH, ptr, tile_ptr, B, N, out, ldo, lse2, drop_seed, drop_thresh,
-                                       S(stream));
+                                       nullptr, nullptr, nullptr, 0, S(stream));
     if (r == hipErrorInvalidValue)
         return bad("gn_attention_fwd", "head width in {8,16,32,64} (fp32) or {32,64} (bf16), row pitches multiples of 16 bytes");
     return fail(r, "gn_attention_fwd");
+}
+int gn_attention_fwd_bits(const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr, const int32_t* tile_ptr,
+                          int32_t B, int32_t N, void* out, int64_t ldo, float* lse2, uint32_t drop_seed, uint32_t drop_thresh,
+                          uint32_t* bits_r, uint32_t* bits_c, const int64_t* evoff, int64_t plane_words, void* stream) {
+    if (H <= 0 || B < 0 || N < 0 || !bits_r || !bits_c || !evoff || plane_words < 0 || drop_thresh == 0)
+        return bad("gn_attention_fwd_bits", "H > 0, B >= 0, N >= 0, drop_thresh != 0, bit planes and event offsets given");
+    hipError_t r = gn::launch_attn_fwd(1, qkv, ld, H, DH, ptr, tile_ptr, B, N, out, ldo, lse2, drop_seed, drop_thresh, bits_r,
+                                       bits_c, reinterpret_cast<const long long*>(evoff), plane_words, S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_attention_fwd_bits", "head width in {32,64}, row pitches multiples of 16 bytes");
+    return fail(r, "gn_attention_fwd_bits");
 }
 int gn_attention_bwd(int32_t lowp, const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr,
                      const int32_t* tile_ptr, int32_t B, int32_t N, const void* out, int64_t ldo, const void* dout,
@@ -332,10 +342,22 @@ int gn_attention_bwd(int32_t lowp, const void* qkv, int64_t ld, int32_t H, int32
                      uint32_t drop_thresh, void* stream) {
     if (H <= 0 || B < 0 || N < 0) return bad("gn_attention_bwd", "H > 0, B >= 0, N >= 0");
     hipError_t r = gn::launch_attn_bwd(lowp, qkv, ld, H, DH, ptr, tile_ptr, B, N, out, ldo, dout, lddo, lse2, delta, dqkv,
-                                       lddq, drop_seed, drop_thresh, S(stream));
+                                       lddq, drop_seed, drop_thresh, nullptr, nullptr, nullptr, 0, S(stream));
     if (r == hipErrorInvalidValue)
         return bad("gn_attention_bwd", "head width in {8,16,32,64} (fp32) or {32,64} (bf16), row pitches multiples of 16 bytes");
     return fail(r, "gn_attention_bwd");
+}
+int gn_attention_bwd_bits(const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr, const int32_t* tile_ptr,
+                          int32_t B, int32_t N, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse2,
+                          float* delta, void* dqkv, int64_t lddq, uint32_t drop_thresh, const uint32_t* bits_r,
+                          const uint32_t* bits_c, const int64_t* evoff, int64_t plane_words, void* stream) {
+    if (H <= 0 || B < 0 || N < 0 || !bits_r || !bits_c || !evoff || plane_words < 0 || drop_thresh == 0)
+        return bad("gn_attention_bwd_bits", "H > 0, B >= 0, N >= 0, drop_thresh != 0, bit planes and event offsets given");
+    hipError_t r = gn::launch_attn_bwd(1, qkv, ld, H, DH, ptr, tile_ptr, B, N, out, ldo, dout, lddo, lse2, delta, dqkv, lddq, 0u,
+                                       drop_thresh, bits_r, bits_c, reinterpret_cast<const long long*>(evoff), plane_words,
+                                       S(stream));
+    if (r == hipErrorInvalidValue) return bad("gn_attention_bwd_bits", "head width in {32,64}, row pitches multiples of 16 bytes");
+    return fail(r, "gn_attention_bwd_bits");
 }
 
 int gn_dropout(const void* x, int64_t ldx, int32_t x_lowp, const float* res, int64_t ldres, void* y, int64_t ldy,

@@ -104,10 +104,12 @@ hipError_t launch_attn_plan(const int* ptr, int B, int* plan, int sorted, hipStr
 // (lowp: qkv / out / dout / dqkv are bf16 and the MFMA kernels run; else fp32 on the vector ALU)
 hipError_t launch_attn_fwd(int lowp, const void* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
                            int B, int N, void* out, long long ldo, float* lse2, unsigned seed, unsigned thresh,
+                           unsigned int* bits_r, unsigned int* bits_c, const long long* evoff, long long plane,
                            hipStream_t st);
 hipError_t launch_attn_bwd(int lowp, const void* qkv, long long ld, int H, int DH, const int* ptr, const int* tile_ptr,
                            int B, int N, const void* out, long long ldo, const void* dout, long long lddo,
                            const float* lse2, float* delta, void* dqkv, long long lddq, unsigned seed, unsigned thresh,
+                           const unsigned int* bits_r, const unsigned int* bits_c, const long long* evoff, long long plane,
                            hipStream_t st);
 // generic.hip: dropout (+ residual add); thresh = round(p * 2^32)
 hipError_t launch_dropout(const void* x, long long ldx, int x_lowp, const float* res, long long ldres, void* y, long long ldy,

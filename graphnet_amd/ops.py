@@ -810,6 +810,61 @@ def attention_fwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, drop: Opt
     return out, lse2
 
 
+def attention_drop_layout(ptr: Tensor) -> Tuple[Tensor, int]:
+    """Where the SAVED dropout decisions of one batch live (``gn_attention_fwd_bits``): ``evoff`` int64 ``[B + 1]`` =
+    running sum of ``ceil(n / 32)^2`` tiles per event, and the words per head plane (32 per tile).  One host
+    synchronisation per batch (the plane size is an allocation size); every DynTrans layer of the step reuses it."""
+    n = (ptr[1:] - ptr[:-1]).to(torch.int64)
+    w = (n + 31) // 32
+    evoff = torch.zeros(int(ptr.shape[0]), dtype=torch.int64, device=ptr.device)
+    torch.cumsum(w * w, 0, out=evoff[1:])
+    return evoff, int(evoff[-1].item()) * 32
+
+
+def attention_fwd_saved(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, drop: Tuple[int, int],
+                        layout: Tuple[Tensor, int]):
+    """:func:`attention_fwd` with dropout (bf16 tensors) that also stores every keep decision as a bit, in both
+    orientations, for :func:`attention_bwd_saved`.  -> (out, lse2, (bits_r, bits_c)); results are bit-identical to
+    :func:`attention_fwd` with the same ``drop``."""
+    _need(qkv, torch.bfloat16, "qkv")
+    N, d3 = int(qkv.shape[0]), int(qkv.shape[1])
+    d = d3 // 3
+    if d3 != 3 * d or d % n_head:
+        raise ValueError("qkv must be [N, 3*d] with d a multiple of the number of heads")
+    if not drop or not drop[1]:
+        raise ValueError("attention_fwd_saved needs a dropout threshold")
+    B = int(ptr.shape[0]) - 1
+    evoff, plane = layout
+    _need(evoff, torch.int64, "evoff")
+    out = torch.empty((N, d), dtype=qkv.dtype, device=qkv.device)
+    lse2 = torch.empty((N, n_head), dtype=torch.float32, device=qkv.device)
+    bits_r = torch.empty(max(n_head * plane, 1), dtype=torch.int32, device=qkv.device)
+    bits_c = torch.empty(max(n_head * plane, 1), dtype=torch.int32, device=qkv.device)
+    with _timed("attention_fwd"):
+        _lib.check(_lib.lib().gn_attention_fwd_bits(_p(qkv), _rows(qkv, "qkv"), n_head, d // n_head, _p(ptr), _p(plan), B, N,
+                                                    _p(out), d, _p(lse2), drop[0] & 0xFFFFFFFF, drop[1], _p(bits_r),
+                                                    _p(bits_c), _p(evoff), plane, _st()))
+    return out, lse2, (bits_r, bits_c)
+
+
+def attention_bwd_saved(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, out: Tensor, lse2: Tensor, dout: Tensor,
+                        thresh: int, bits: Tuple[Tensor, Tensor], layout: Tuple[Tensor, int]) -> Tensor:
+    """Gradient of :func:`attention_fwd_saved` w.r.t. ``qkv``: the keep decisions are read from ``bits``."""
+    _need(qkv, torch.bfloat16, "qkv"); _need(dout, qkv.dtype, "dout"); _need(out, qkv.dtype, "out")
+    N, d3 = int(qkv.shape[0]), int(qkv.shape[1])
+    d = d3 // 3
+    B = int(ptr.shape[0]) - 1
+    evoff, plane = layout
+    dqkv = torch.empty((N, d3), dtype=qkv.dtype, device=qkv.device)
+    delta = torch.empty((N, n_head), dtype=torch.float32, device=qkv.device)
+    with _timed("attention_bwd"):
+        _lib.check(_lib.lib().gn_attention_bwd_bits(_p(qkv), _rows(qkv, "qkv"), n_head, d // n_head, _p(ptr), _p(plan), B, N,
+                                                    _p(out), _rows(out, "out"), _p(dout), _rows(dout, "dout"), _p(lse2),
+                                                    _p(delta), _p(dqkv), d3, thresh, _p(bits[0]), _p(bits[1]), _p(evoff),
+                                                    plane, _st()))
+    return dqkv
+
+
 def attention_bwd(qkv: Tensor, n_head: int, ptr: Tensor, plan: Tensor, out: Tensor, lse2: Tensor, dout: Tensor,
                   drop: Optional[Tuple[int, int]] = None) -> Tensor:
     """Gradient of :func:`attention_fwd` w.r.t. ``qkv`` -> [N, 3 d] in qkv's type (``out`` / ``dout`` likewise)."""

@@ -86,7 +86,14 @@ class _DynTransFunction(torch.autograd.Function):
         qkv = ops.linear_fwd(mode, _ksegs([(y0g, d)]), _wt(mode, Win, [d]), 3 * d, bias=bin_.contiguous(), out_lowp=lowp)
         drop = cfg.get("drop")                      # None, or (thresh, [seed_attn, seed_1, seed_ffn, seed_2])
         th = drop[0] if drop else 0
-        att, lse2 = ops.attention_fwd(qkv, H, ptr, plan, drop=(drop[1][0], th) if drop else None)
+        # dropout on the attention probabilities: the matrix-core kernels save their keep decisions as bits (both
+        # orientations) so that the two backward passes read them instead of re-evaluating the hash
+        dlay = cfg.get("drop_layout") if drop and lowp else None
+        dbits = None
+        if dlay is not None:
+            att, lse2, dbits = ops.attention_fwd_saved(qkv, H, ptr, plan, (drop[1][0], th), dlay)
+        else:
+            att, lse2 = ops.attention_fwd(qkv, H, ptr, plan, drop=(drop[1][0], th) if drop else None)
         if drop:                                    # x + dropout1(self_attn(x))
             proj = ops.linear_fwd(mode, _ksegs([(att, d)]), _wt(mode, Wout, [d]), d, bias=bout.contiguous())
             z1 = ops.dropout(proj, drop[1][1], th, res=y0)
@@ -109,6 +116,7 @@ class _DynTransFunction(torch.autograd.Function):
         ctx.cfg, ctx.p = cfg, p
         ctx.saved = (xin, Fin, a1, z2, aux, residual, r, st0, y0g, qkv, att, lse2, z1, st1, y1g, h, z3, st2)
         ctx.fused = (PQ, conv16, esaved) if fused else None
+        ctx.dbits = dbits
         return y2
 
     @staticmethod
@@ -151,7 +159,10 @@ class _DynTransFunction(torch.autograd.Function):
         dproj = ops.dropout(dz1, drop[1][1], th, out=torch.empty_like(dz1, dtype=ops.mode_dtype(mode))) if drop else dz1g
         grads[8], grads[9] = ops.linear_wgrad(mode, dproj, d, _ksegs([(att, d)]), with_bias=True)
         datt = ops.linear_fwd(mode, _ksegs([(dproj, d)]), _wt(mode, Wout.t(), [d]), d, out_lowp=qkv.dtype == torch.bfloat16)
-        dqkv = ops.attention_bwd(qkv, H, ptr, plan, att, lse2, datt, drop=(drop[1][0], th) if drop else None)
+        if ctx.dbits is not None:
+            dqkv = ops.attention_bwd_saved(qkv, H, ptr, plan, att, lse2, datt, th, ctx.dbits, cfg["drop_layout"])
+        else:
+            dqkv = ops.attention_bwd(qkv, H, ptr, plan, att, lse2, datt, drop=(drop[1][0], th) if drop else None)
         grads[6], grads[7] = ops.linear_wgrad(mode, dqkv, 3 * d, _ksegs([(y0, d)]), with_bias=True)
         ops.linear_fwd(mode, _ksegs([(dqkv, 3 * d)]), _wt(mode, Win.t(), [3 * d]), d, out=dz1, accum=True)  # dy0
         # DynTrans.norm1
@@ -397,6 +408,9 @@ class DynEdgeTITO(GNN):
             exact = None
         cfg = {"mode": self._compute_mode, "graph": table, "graph_exact": exact, "ptr": ptr32, "batch": batch32, "plan": plan,
                "seed_log": seed_log if return_trace else None}
+        if self.training and self._compute_mode == ops.MODE_BF16 and getattr(self, "_save_drop_bits", True) and \
+                any(getattr(l, "_dropout", 0.0) > 0.0 for l in self._conv_layers):
+            cfg["drop_layout"] = ops.attention_drop_layout(ptr32)
         conv_out = []
         for conv in self._conv_layers:
             x = conv(x, cfg)

@@ -35,7 +35,7 @@ extern "C" {
 #define GN_MAXSEG 6
 
 const char* gn_last_error(void);
-#define GN_ABI_VERSION 3   /* 2: gn_edgeconv_fwd takes the real hidden width H1; 3: gn_edgeconv_max_* (EdgeConvTito) */
+#define GN_ABI_VERSION 4   /* 2: gn_edgeconv_fwd takes the real hidden width H1; 3: gn_edgeconv_max_* (EdgeConvTito); 4: gn_attention_*_bits */
 int gn_abi_version(void);   /* == GN_ABI_VERSION of the header the library was built from */
 
 /* ---- graph construction ------------------------------------------------------------- */
@@ -294,6 +294,22 @@ int gn_attention_bwd(int32_t lowp, const void* qkv, int64_t ld, int32_t H, int32
                      const int32_t* tile_ptr, int32_t B, int32_t N, const void* out, int64_t ldo, const void* dout,
                      int64_t lddo, const float* lse2, float* delta, void* dqkv, int64_t lddq, uint32_t drop_seed,
                      uint32_t drop_thresh, void* stream);
+
+/* The same with the dropout decisions SAVED (bf16 tensors, matrix-core kernels only; ABI 4): the forward evaluates the
+ * keep rule and also stores every decision as a bit, once per orientation, the backward reads the bits instead of
+ * re-evaluating the hash twice per probability.  An event of n pulses has W = ceil(n / 32) blocks per side and W * W
+ * tiles of 32 words; evoff[B + 1] (int64, device) = running sum of W * W over the events in ptr order;
+ * plane_words = 32 * evoff[B]; bits_r / bits_c: uint32[H * plane_words] each:
+ *   bits_r: tile (query block qb, key block kb) at evoff[e] + qb * W + kb, word c = the 32 key bits of query 32 qb + c
+ *   bits_c: tile (key block kb, query block qb) at evoff[e] + kb * W + qb, word c = the 32 query bits of key 32 kb + c
+ * Same results as gn_attention_fwd / gn_attention_bwd with the same seed and threshold, bit for bit. */
+int gn_attention_fwd_bits(const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr, const int32_t* tile_ptr,
+                          int32_t B, int32_t N, void* out, int64_t ldo, float* lse2, uint32_t drop_seed, uint32_t drop_thresh,
+                          uint32_t* bits_r, uint32_t* bits_c, const int64_t* evoff, int64_t plane_words, void* stream);
+int gn_attention_bwd_bits(const void* qkv, int64_t ld, int32_t H, int32_t DH, const int32_t* ptr, const int32_t* tile_ptr,
+                          int32_t B, int32_t N, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse2,
+                          float* delta, void* dqkv, int64_t lddq, uint32_t drop_thresh, const uint32_t* bits_r,
+                          const uint32_t* bits_c, const int64_t* evoff, int64_t plane_words, void* stream);
 
 /* ---- dropout (torch.nn.Dropout inside TransformerEncoderLayer / MultiheadAttention, layers.py:149-160) ---- */
 /* Counter-based: element (r, c) of stream `seed` is kept iff mix32(mix32(seed ^ r*0x9E3779B1) ^ c*0x85EBCA77) >=

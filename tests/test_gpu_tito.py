@@ -87,6 +87,43 @@ def test_ragged_attention_forward_backward(H, dh, p_drop):
         for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
             assert rel_err(dqkv1[:, sl], ref.grad[:, sl]) < 3e-2, name
             assert norm_err(dqkv1[:, sl], ref.grad[:, sl]) < 1.5e-2, name
+        if drop:
+            # the same with the keep decisions SAVED by the forward and read by both backward passes: bit for bit the
+            # results of the hash-evaluating kernels, and the stored words equal the replica of the keep rule
+            lay = ops.attention_drop_layout(ptr_d)
+            out2, lse2b, bits = ops.attention_fwd_saved(xb, H, ptr_d, plan, drop, lay)
+            assert torch.equal(out2, out1) and torch.equal(lse2b, lse1)
+            dqkv2 = ops.attention_bwd_saved(xb, H, ptr_d, plan, out2, lse2b, w.to(torch.bfloat16).to(DEV), drop[1], bits, lay)
+            assert torch.equal(dqkv2, dqkv1)
+            import numpy as np
+            from oracle.tito_oracle import keep_mask
+            evoff = lay[0].cpu().numpy()
+            br = bits[0].cpu().numpy().view(np.uint32).reshape(H, lay[1])
+            bc = bits[1].cpu().numpy().view(np.uint32).reshape(H, lay[1])
+            for e in (1, 4):                               # a 63-pulse and a 200-pulse event
+                n, W = sizes[e], (sizes[e] + 31) // 32
+                rows = np.arange(ptr[e], ptr[e + 1], dtype=np.uint32)
+                for head in (0, H - 1):
+                    cols = (rows * np.uint32(H) + np.uint32(head)).astype(np.uint32)
+                    keep = keep_mask(drop[0], rows[:, None], cols[None, :], drop[1])      # [query, key]
+                    for qb in range(W):
+                        for kb in range(W):
+                            tr = br[head, (evoff[e] + qb * W + kb) * 32:][:32]
+                            tc = bc[head, (evoff[e] + kb * W + qb) * 32:][:32]
+                            for c in range(32):
+                                q = 32 * qb + c
+                                if q >= n:
+                                    continue
+                                ks = np.arange(32 * kb, min(32 * kb + 32, n))
+                                got = (tr[c] >> (ks - 32 * kb).astype(np.uint32)) & 1
+                                assert np.array_equal(got.astype(bool), keep[q, ks]), (e, head, qb, kb, c)
+                            for c in range(32):
+                                k = 32 * kb + c
+                                if k >= n:
+                                    continue
+                                qs = np.arange(32 * qb, min(32 * qb + 32, n))
+                                got = (tc[c] >> (qs - 32 * qb).astype(np.uint32)) & 1
+                                assert np.array_equal(got.astype(bool), keep[qs, k]), (e, head, kb, qb, c)
     else:
         with pytest.raises(RuntimeError, match="head width"):
             ops.attention_fwd(x.to(torch.bfloat16), H, ptr_d, plan)
