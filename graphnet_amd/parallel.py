@@ -34,20 +34,25 @@ class FlatGradAllReduce:
             off += p.numel()
 
     def zero_grad(self) -> None:
-        """Use instead of ``optimizer.zero_grad(set_to_none=True)`` so the views survive."""
-        self.flat.zero_()
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        """Use instead of ``optimizer.zero_grad()``: ``.grad`` is dropped, so that autograd hands over each
+        freshly computed gradient tensor as it is (no ``grad += new`` kernel per parameter); :meth:`gather_into_flat`
+        then moves all of them into the flat buffer with one multi-tensor copy."""
+        for p in self.params:
+            p.grad = None
 
     def gather_into_flat(self) -> None:
-        """autograd may have replaced ``.grad`` (first accumulation): copy back into the flat buffer."""
+        """Copy every parameter's gradient into its view of the flat buffer (ONE ``_foreach_copy_`` launch group
+        instead of a kernel per parameter) and make the views the ``.grad`` tensors the optimizer steps on."""
+        dst, src = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
-                p.grad = v
             elif p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
-                p.grad = v
+                dst.append(v)
+                src.append(p.grad.reshape(v.shape) if p.grad.shape != v.shape else p.grad)
+            p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def all_reduce(self) -> None:
         """ONE sum-all-reduce of the flat gradient (RCCL over xGMI / gloo on CPU)."""
