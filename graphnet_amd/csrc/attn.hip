@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(
             for (int t = 0; t < 8; ++t) {
                 float p = exp2f(s[t] - mn);
                 l += p;
-                if constexpr (DROP) p = gn_keep(dr.seed, (unsigned)qi, (unsigned)((kt + c + t) * H + head), dr.thresh) ? p * dr.inv : 0.0f;
+                if constexpr (DROP) p = gn_attn_keep(dr.seed, (unsigned)qi, (unsigned)(kt + c + t - kbeg), (unsigned)H, (unsigned)head, dr.thresh) ? p * dr.inv : 0.0f;
                 const float* vr = Vs + (c + t) * DH;
 #pragma unroll
                 for (int d4 = 0; d4 < DH / 4; ++d4) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(
                         dp = fmaf(go[4 * d4], vv.x, dp); dp = fmaf(go[4 * d4 + 1], vv.y, dp);
                         dp = fmaf(go[4 * d4 + 2], vv.z, dp); dp = fmaf(go[4 * d4 + 3], vv.w, dp);
                     }
-                    if constexpr (DROP) dp = gn_keep(dr.seed, (unsigned)qi, (unsigned)((kt + c + t) * H + head), dr.thresh) ? dp * dr.inv : 0.0f;
+                    if constexpr (DROP) dp = gn_attn_keep(dr.seed, (unsigned)qi, (unsigned)(kt + c + t - kbeg), (unsigned)H, (unsigned)head, dr.thresh) ? dp * dr.inv : 0.0f;
                     const float ds = exp2f(s - ls) * (dp - dl);
 #pragma unroll
                     for (int d4 = 0; d4 < DH / 4; ++d4) {
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(
                     const float p0 = exp2f(s - Ls[c + t]);
                     float p = p0;
                     if constexpr (DROP) {
-                        const bool keep = gn_keep(dr.seed, (unsigned)(qt + c + t), (unsigned)(kj * H + head), dr.thresh);
+                        const bool keep = gn_attn_keep(dr.seed, (unsigned)(qt + c + t), (unsigned)(kj - kbeg), (unsigned)H, (unsigned)head, dr.thresh);
                         p = keep ? p0 * dr.inv : 0.0f;
                         dp = keep ? dp * dr.inv : 0.0f;
                     }
@@ -430,12 +430,17 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(
             const float corr = exp2f(m[g] - mn);
             float ps = 0.0f;
             unsigned int roww = 0u;                     // BITS: this lane's 16 keep decisions, bit = key - kt - 4h
+            unsigned int pairh = 0u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 s[r] = exp2f(fmaf(s[r], scale2, -mn));
                 ps += s[r];
                 if constexpr (DROP) {
-                    const bool keep = gn_keep(dr.seed, (unsigned)(q0 + 32 * g + c), (unsigned)((kt + acc_row(r, h)) * H + head), dr.thresh);
+                    // registers r (even) and r + 1 hold keys 2m, 2m + 1 of the event (kt - kbeg and acc_row(r, h) are even)
+                    if ((r & 1) == 0)
+                        pairh = gn_attn_pair_hash(dr.seed, (unsigned)(q0 + 32 * g + c), (unsigned)((kt - kbeg + acc_row(r, h)) >> 1),
+                                                  (unsigned)H, (unsigned)head);
+                    const bool keep = gn_attn_keep_half(pairh, r & 1, dr.thresh);
                     s[r] = keep ? s[r] * dr.inv : 0.0f;
                     if constexpr (BITS) roww |= keep ? (1u << acc_row(r, 0)) : 0u;
                 }
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_mfma_kernel(
                         const float sc = dpr * dr.inv;
                         dpr = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, sc) & attn_keep_mask(wsh[g], r));
                     } else {
-                        dpr = gn_keep(dr.seed, (unsigned)(q0 + 32 * g + c), (unsigned)((kt + acc_row(r, h)) * H + head), dr.thresh) ? dpr * dr.inv : 0.0f;
+                        dpr = gn_attn_keep(dr.seed, (unsigned)(q0 + 32 * g + c), (unsigned)(kt - kbeg + acc_row(r, h)), (unsigned)H, (unsigned)head, dr.thresh) ? dpr * dr.inv : 0.0f;
                     }
                 }
                 s[r] = p * (dpr - dl[g]);
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_mfma_kernel(
                         pd = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, p * dr.inv) & km);
                         dpr = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, dpr * dr.inv) & km);
                     } else {
-                        const bool keep = gn_keep(dr.seed, (unsigned)(qt + acc_row(r, h)), (unsigned)((k0 + 32 * g + c) * H + head), dr.thresh);
+                        const bool keep = gn_attn_keep(dr.seed, (unsigned)(qt + acc_row(r, h)), (unsigned)(k0 - kbeg + 32 * g + c), (unsigned)H, (unsigned)head, dr.thresh);
                         pd = keep ? p * dr.inv : 0.0f;
                         dpr = keep ? dpr * dr.inv : 0.0f;
                     }

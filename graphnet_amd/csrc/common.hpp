@@ -177,6 +177,21 @@ __host__ __device__ __forceinline__ unsigned int gn_mix32(unsigned int x) {
 __host__ __device__ __forceinline__ bool gn_keep(unsigned int seed, unsigned int a, unsigned int b, unsigned int thresh) {
     return gn_mix32(gn_mix32(seed ^ (a * 0x9E3779B1u)) ^ (b * 0x85EBCA77u)) >= thresh;
 }
+// Attention probabilities (query a, key, head): ONE hash decides a PAIR of keys.  kl = key index inside its event;
+// keys 2m and 2m+1 take the low / high halfword of the hash of (stream, query, m * H + head), kept iff the halfword is
+// >= thresh >> 16 (p resolved to 2^-16).  The forward is the only kernel that evaluates the rule when the decisions are
+// saved as bits (gn_attention_fwd_bits); half the hashes there.
+__host__ __device__ __forceinline__ unsigned int gn_attn_pair_hash(unsigned int seed, unsigned int a, unsigned int pair,
+                                                                    unsigned int H, unsigned int head) {
+    return gn_mix32(gn_mix32(seed ^ (a * 0x9E3779B1u)) ^ ((pair * H + head) * 0x85EBCA77u));
+}
+__host__ __device__ __forceinline__ bool gn_attn_keep_half(unsigned int hash, unsigned int odd, unsigned int thresh) {
+    return ((odd ? hash >> 16 : hash & 0xffffu)) >= (thresh >> 16);
+}
+__host__ __device__ __forceinline__ bool gn_attn_keep(unsigned int seed, unsigned int a, unsigned int kl, unsigned int H,
+                                                      unsigned int head, unsigned int thresh) {
+    return gn_attn_keep_half(gn_attn_pair_hash(seed, a, kl >> 1, H, head), kl & 1u, thresh);
+}
 struct Drop { unsigned int seed, thresh; float inv; };   // inv = 1 / (1 - thresh / 2^32)
 
 // neighbour table + overflow list of one layer's graph

@@ -316,7 +316,9 @@ int gn_attention_bwd_bits(const void* qkv, int64_t ld, int32_t H, int32_t DH, co
  * thresh, thresh = round(p * 2^32), kept values are scaled by 1 / (1 - thresh / 2^32); nothing is stored, the
  * backward recomputes the decisions from the same seed (apply gn_dropout to the gradient).  thresh = 0 disables.
  * y[r, c] = (res ? res[r, c] : 0) + dropout(x)[r, c]; x / y fp32 or bf16 (in place allowed), res fp32.
- * The attention kernels drop the softmax probabilities with r = query row, c = key row * H + head. */
+ * The attention kernels drop the softmax probabilities with ONE hash per (query row q, pair of keys, head): keys 2m and
+ * 2m + 1 of an event (indices inside the event) take the low / high halfword of
+ * mix32(mix32(seed ^ q*0x9E3779B1) ^ (m*H + head)*0x85EBCA77), kept iff the halfword >= thresh >> 16. */
 int gn_dropout(const void* x, int64_t ldx, int32_t x_lowp, const float* res, int64_t ldres, void* y, int64_t ldy,
                int32_t y_lowp, int64_t rows, int32_t cols, uint32_t seed, uint32_t thresh, void* stream);
 

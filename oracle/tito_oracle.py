@@ -60,6 +60,18 @@ def keep_mask(seed: int, a: np.ndarray, b: np.ndarray, thresh: int) -> np.ndarra
     return _mix32(h ^ ((b * np.uint64(0x85EBCA77)) & _M32)) >= np.uint64(thresh)
 
 
+def keep_mask_attn(seed: int, q: np.ndarray, kl: np.ndarray, head: np.ndarray, n_head: int, thresh: int) -> np.ndarray:
+    """Attention probabilities: one hash per (query ``q`` - global pulse index -, PAIR of keys, head); ``kl`` = key index
+    inside its event; keys 2m, 2m+1 take the low / high halfword of
+    mix32(mix32(seed ^ q*0x9E3779B1) ^ (m*H + head)*0x85EBCA77), kept iff halfword >= thresh >> 16."""
+    q = np.asarray(q, dtype=np.uint64); kl = np.asarray(kl, dtype=np.uint64); head = np.asarray(head, dtype=np.uint64)
+    h = _mix32(np.uint64(seed & 0xFFFFFFFF) ^ ((q * np.uint64(0x9E3779B1)) & _M32))
+    pair = ((kl >> np.uint64(1)) * np.uint64(n_head) + head) & _M32
+    x = _mix32(h ^ ((pair * np.uint64(0x85EBCA77)) & _M32))
+    half = np.where((kl & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))
+    return half >= np.uint64(thresh >> 16)
+
+
 def dropout_rc(x: Tensor, seed: int, thresh: int) -> Tensor:
     """Element (row, col) kept by the rule above, kept values scaled by 1 / (1 - thresh / 2^32)."""
     r = np.arange(x.shape[0])[:, None]; c = np.arange(x.shape[1])[None, :]
@@ -98,7 +110,7 @@ def self_attention_ragged(x: Tensor, ptr: Sequence[int], in_w: Tensor, in_b: Ten
             qg = np.arange(a, b)[None, :, None]
             kg = np.arange(a, b)[None, None, :]
             hd = np.arange(n_head)[:, None, None]
-            keep = keep_mask(seed, qg, kg * n_head + hd, thresh)
+            keep = keep_mask_attn(seed, qg, kg - a, hd, n_head, thresh)
             p = p * torch.from_numpy(keep.astype(np.float32) * np.float32(1.0 / (1.0 - thresh / 4294967296.0)))
         outs.append((p @ ve).transpose(0, 1).reshape(n, d))
     o = torch.cat(outs, dim=0) if outs else x.new_zeros((0, d))

@@ -41,8 +41,8 @@ def _ragged_attention_reference(qkv: torch.Tensor, ptr, H: int, drop=None) -> to
         ve = v[a:b].reshape(n, H, dh).transpose(0, 1)
         p = torch.softmax(qe @ ke.transpose(1, 2) / math.sqrt(dh), dim=-1)
         if drop is not None:
-            keep = tito_oracle.keep_mask(drop[0], np.arange(a, b)[None, :, None],
-                                         np.arange(a, b)[None, None, :] * H + np.arange(H)[:, None, None], drop[1])
+            keep = tito_oracle.keep_mask_attn(drop[0], np.arange(a, b)[None, :, None], np.arange(n)[None, None, :],
+                                              np.arange(H)[:, None, None], H, drop[1])
             p = p * torch.from_numpy(keep.astype(np.float64) / (1.0 - drop[1] / 4294967296.0))
         outs.append((p @ ve).transpose(0, 1).reshape(n, d))
     return torch.cat(outs, 0)
@@ -96,7 +96,7 @@ def test_ragged_attention_forward_backward(H, dh, p_drop):
             dqkv2 = ops.attention_bwd_saved(xb, H, ptr_d, plan, out2, lse2b, w.to(torch.bfloat16).to(DEV), drop[1], bits, lay)
             assert torch.equal(dqkv2, dqkv1)
             import numpy as np
-            from oracle.tito_oracle import keep_mask
+            from oracle.tito_oracle import keep_mask_attn
             evoff = lay[0].cpu().numpy()
             br = bits[0].cpu().numpy().view(np.uint32).reshape(H, lay[1])
             bc = bits[1].cpu().numpy().view(np.uint32).reshape(H, lay[1])
@@ -104,8 +104,7 @@ def test_ragged_attention_forward_backward(H, dh, p_drop):
                 n, W = sizes[e], (sizes[e] + 31) // 32
                 rows = np.arange(ptr[e], ptr[e + 1], dtype=np.uint32)
                 for head in (0, H - 1):
-                    cols = (rows * np.uint32(H) + np.uint32(head)).astype(np.uint32)
-                    keep = keep_mask(drop[0], rows[:, None], cols[None, :], drop[1])      # [query, key]
+                    keep = keep_mask_attn(drop[0], rows[:, None], np.arange(n)[None, :], head, H, drop[1])     # [query, key]
                     for qb in range(W):
                         for kb in range(W):
                             tr = br[head, (evoff[e] + qb * W + kb) * 32:][:32]

@@ -394,6 +394,21 @@ def test_dropout_keep_rule_replica_properties():
     assert abs(k1[:, ::2].mean() - k1[:, 1::2].mean()) < 5e-3 and abs(k1[::2].mean() - k1[1::2].mean()) < 5e-3
     with pytest.raises(ValueError):
         ops.drop_thresh(1.0)
+    # attention probabilities: one hash per (query, PAIR of keys, head), the halfwords decide keys 2m / 2m + 1
+    q = np.arange(3000, 4500)[:, None, None]
+    kl = np.arange(600)[None, :, None]
+    hd = np.arange(8)[None, None, :]
+    a1 = tito_oracle.keep_mask_attn(77, q, kl, hd, 8, th)
+    assert a1.shape == (1500, 600, 8) and abs(a1.mean() - 0.9) < 1e-3
+    assert np.array_equal(a1, tito_oracle.keep_mask_attn(77, q, kl, hd, 8, th))
+    lo, hi = a1[:, 0::2], a1[:, 1::2]                       # the two keys of a pair: independent decisions
+    assert abs(lo.mean() - hi.mean()) < 2e-3
+    assert abs((lo & hi).mean() - lo.mean() * hi.mean()) < 2e-3
+    for ax in range(3):                                     # neighbours along query / key pair / head: independent
+        x, y = np.take(lo, range(0, lo.shape[ax] - 1), ax), np.take(lo, range(1, lo.shape[ax]), ax)
+        assert abs((x & y).mean() - x.mean() * y.mean()) < 2e-3, ax
+    assert 0.15 < (a1 != tito_oracle.keep_mask_attn(78, q, kl, hd, 8, th)).mean() < 0.21
+    assert tito_oracle.keep_mask_attn(5, q, kl, hd, 8, 0).all()
 
 
 def test_flat_buffer_batch_equals_per_event_path():
