@@ -1276,8 +1276,15 @@ __global__ __launch_bounds__(NW * 64) void edge_dw2_v3_kernel(
             e[jj] = ((t >> (2 * jj)) & 1 ? 0x0000ffffu : 0u) | ((t >> (2 * jj + 1)) & 1 ? 0xffff0000u : 0u);
         *reinterpret_cast<u32x4*>(&MaskLut[t * 16]) = e;
     }
-    const int half = (int)blockIdx.x % HALVES, part = (int)blockIdx.x / HALVES;
+    // The HALVES workgroups of a tile range read the same g_out rows, slot bytes and neighbour ids: place them on the
+    // same XCD (blockIdx -> XCD is round-robin over 8) so that the second reader hits that XCD's L2
     const int nparts = ((int)gridDim.x + HALVES - 1) / HALVES;
+    int half = (int)blockIdx.x % HALVES, part = (int)blockIdx.x / HALVES;
+    if (HALVES == 2 && (nparts & 7) == 0 && (int)gridDim.x == 2 * nparts) {
+        const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        half = slot & 1;
+        part = (slot >> 1) * 8 + xcd;
+    }
     const unsigned char* PQb = reinterpret_cast<const unsigned char*>(PQ);
     const unsigned char* goutb = reinterpret_cast<const unsigned char*>(gout);
     const unsigned int ldg2 = (unsigned int)ldg * 2u;

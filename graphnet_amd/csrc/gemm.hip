@@ -315,8 +315,12 @@ __device__ __forceinline__ void tn2_read(Tn2Frags& f, const unsigned char* pa, c
 // PIPE: the transposed fragments of k-step s+1 are requested before the MFMAs of k-step s (two fragment sets).  The
 // variants with fp32 dY hold twice the staging registers and run with ONE set (PIPE = false): with two they spill
 // (20-68 bytes of scratch), and no kernel of this library may use scratch (hipGraph replay).
-template <bool ONES, bool PIPE>
-__device__ __forceinline__ void tn2_tile(const unsigned char* ya, const unsigned char* xb, f32x16 (&acc)[4], f32x16& accb) {
+struct Tn2NoSide { __device__ __forceinline__ void operator()(int) const {} };
+// side(s): work of the caller placed behind the MFMAs of k-step s (the LDS writes of the NEXT tile's staged rows: they
+// go to the other buffer, and on their own - after the MFMAs, before the barrier - they cost ~a third of a tile's time)
+template <bool ONES, bool PIPE, typename Side = Tn2NoSide>
+__device__ __forceinline__ void tn2_tile(const unsigned char* ya, const unsigned char* xb, f32x16 (&acc)[4], f32x16& accb,
+                                         const Side& side = Side()) {
     constexpr int YP = tr_pitch_g(256 * 2), XP = tr_pitch_g(128 * 2);
     bf16x8 ones;
 #pragma unroll
@@ -336,6 +340,7 @@ __device__ __forceinline__ void tn2_tile(const unsigned char* ya, const unsigned
         for (int nb = 0; nb < 4; ++nb)
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv[nb]), acc[nb], 0, 0, 0);
         if constexpr (ONES) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb, 0, 0, 0);
+        side(s);
         __builtin_amdgcn_sched_barrier(0);            // keep the next step's reads ahead of this step's MFMAs
     }
 }
@@ -475,17 +480,32 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_v2_kernel(
 #define GN_TN2_MMA(buf_) { if (BIAS && first_k) tn2_tile<BIAS, sizeof(DYT) == 2>(&Ys[buf_][ya_off], &Xs[buf_][xb_off], acc, accb); \
                            else tn2_tile<false, sizeof(DYT) == 2>(&Ys[buf_][ya_off], &Xs[buf_][xb_off], acc, accb); }
     if constexpr (DEEP) {
-        // two tiles per trip: set 0 holds tile+1 / tile+3, set 1 holds tile+2 / tile+4
+        // two tiles per trip: set 0 holds tile+1 / tile+3, set 1 holds tile+2 / tile+4.  The staged rows of the next tile
+        // are written to the other LDS buffer BETWEEN the k-steps of this tile's MFMAs (4 dY chunks + 2 X chunks over
+        // 4 k-steps), not after them.
+#define GN_TN2_MMA_W(buf_, yr, xr)                                                                          \
+    {                                                                                                       \
+        auto side__ = [&](int s) {                                                                          \
+            if (s < 2) {                                                                                    \
+                _Pragma("unroll") for (int j = 2 * s; j < 2 * s + 2; ++j)                                   \
+                    *reinterpret_cast<u32x4*>(&Ys[(buf_) ^ 1][srow * YP + (sc + 8 * j) * 16]) = pack_chunk8(yr[j]); \
+            } else {                                                                                        \
+                *reinterpret_cast<u32x4*>(&Xs[(buf_) ^ 1][srow * XP + (sc + 8 * (s - 2)) * 16]) = pack_chunk8(xr[s - 2]); \
+            }                                                                                               \
+        };                                                                                                  \
+        if (BIAS && first_k) tn2_tile<BIAS, true>(&Ys[buf_][ya_off], &Xs[buf_][xb_off], acc, accb, side__);  \
+        else tn2_tile<false, true>(&Ys[buf_][ya_off], &Xs[buf_][xb_off], acc, accb, side__);                \
+    }
         for (; tile < tile_end; tile += 2) {
-            GN_TN2_MMA(0);
-            GN_TN2_WRITE(1, yr0, xr0);                  // tile + 1 (requested two tiles ago)
+            GN_TN2_MMA_W(0, yr0, xr0);                  // multiplies buffer 0, writes tile + 1 (requested two tiles ago) into 1
             GN_TN2_LOAD(tile + 3, yr0, xr0);
             __syncthreads();
-            if (tile + 1 < tile_end) GN_TN2_MMA(1);     // workgroup-uniform
-            GN_TN2_WRITE(0, yr1, xr1);                  // tile + 2
+            if (tile + 1 < tile_end) { GN_TN2_MMA_W(1, yr1, xr1); }     // workgroup-uniform; writes tile + 2 into buffer 0
+            else { GN_TN2_WRITE(0, yr1, xr1); }
             GN_TN2_LOAD(tile + 4, yr1, xr1);
             __syncthreads();
         }
+#undef GN_TN2_MMA_W
     } else {
         int buf = 0;
         for (; tile < tile_end; ++tile, buf ^= 1) {
